@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE (labhamlet/wavjepa at
+/root/reference, imported with the stub recipe of `_ref_import.py`).
+
+Runs only in the build container (the reference does not exist on the GPU box).  Re-run with
+    python tests/golden/make_golden.py
+The fixtures are data only (inputs + the reference's outputs); no reference source is stored.
+
+Fixtures written:
+  tiny_model.npz      tiny JEPA (conv 32ch, d=64/2 layers, predictor d=32/2 layers): the reference's own
+                      random-init state_dict, masks, audio, fp32 forward outputs, all parameter gradients'
+                      norms + two full gradients, bf16-autocast(CPU) loss.
+  tiny_traj.npz       12 optimisation steps of the tiny model in the reference's order
+                      (training_step incl. EMA -> backward -> clip 5 -> AdamW -> scheduler) with a 3-step
+                      warm-up, and 4 steps with the stock 100 000-step warm-up: losses, grad norms, final
+                      parameter checksums.
+  masks.npz           maskers under a pinned numpy Generator sequence (AudioSet + LibriSpeech settings).
+  crops.npz           on_after_batch_transfer inputs/outputs for a pinned torch seed.
+  base_forward.npz    base model (d=768/12 layers, predictor 384/12, conv 512ch) with hash-synthesised
+                      weights (tests/golden/synth.py), N=2: loss, per-group grad norms, tensor slices.
+  misc.npz            sin-cos tables slices/checksums, EMA decay schedule, LR schedule samples.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_import import import_reference  # noqa: E402
+import synth  # noqa: E402
+
+R = import_reference()
+import transformers  # noqa: E402
+
+TINY_SPEC = [(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)]
+BASE_SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)]
+
+
+def build_ref(spec, d_enc, nh_enc, L_enc, d_dec, nh_dec, L_dec, top_k, seconds=2.01, samples=2, size="base"):
+    ext = R.ConvFeatureExtractor(conv_layers_spec=list(spec), in_channels=1)
+    return R.jepa.JEPA(
+        feature_extractor=ext,
+        transformer_encoder_cfg=R.TransformerEncoderCFG.create(num_layers=L_enc),
+        transformer_encoder_layers_cfg=R.TransformerLayerCFG.create(d_model=d_enc, nhead=nh_enc),
+        transformer_decoder_cfg=R.TransformerEncoderCFG.create(num_layers=L_dec),
+        transformer_decoder_layers_cfg=R.TransformerLayerCFG.create(d_model=d_dec, nhead=nh_dec),
+        lr=4e-4, adam_betas=(0.9, 0.98), adam_weight_decay=0.04,
+        average_top_k_layers=top_k, process_audio_seconds=seconds, nr_samples_per_audio=samples, size=size)
+
+
+class PinnedRng:
+    """Replaces np.random.default_rng so that the k-th call returns default_rng(base + k)."""
+
+    def __init__(self, base):
+        self.base, self.k, self._orig = base, 0, np.random.default_rng
+
+    def __call__(self, seed=None):
+        g = self._orig(self.base + self.k)
+        self.k += 1
+        return g
+
+    def __enter__(self):
+        np.random.default_rng = self
+        return self
+
+    def __exit__(self, *a):
+        np.random.default_rng = self._orig
+
+
+def sd_numpy(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def gen_masks():
+    out = {}
+    with PinnedRng(1000):
+        mk = R.masking.TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10,
+                                              target_prob=0.25, target_length=10, ratio_cutoff=0.1)
+        c, t, v = mk(batch_size=8, n_times=200, in_channels=1)
+    out.update(as_ctx=c.numpy(), as_tgt=t.numpy(), as_vis=v.numpy(), as_base=1000)
+    with PinnedRng(5000):
+        mk = R.masking.SpeechMasker(target_masks_per_context=4, target_prob=0.1, target_length=10, ratio_cutoff=0.5,
+                                    min_context_len=5)
+        c, t, v = mk(batch_size=8, n_times=200, in_channels=1)
+    out.update(ls_ctx=c.numpy(), ls_tgt=t.numpy(), ls_vis=v.numpy(), ls_base=5000)
+    with PinnedRng(9000):
+        mk = R.masking.TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10,
+                                              target_prob=0.25, target_length=10, ratio_cutoff=0.1)
+        c, t, v = mk(batch_size=4, n_times=400, in_channels=1)
+    out.update(as400_ctx=c.numpy(), as400_tgt=t.numpy(), as400_vis=v.numpy(), as400_base=9000)
+    np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
+    return out
+
+
+def gen_tiny(masks):
+    torch.manual_seed(1234)
+    m = build_ref(TINY_SPEC, 64, 4, 2, 32, 4, 2, top_k=2)
+    # make biases / norm params non-trivial so that every term is exercised
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.add_(0.02 * torch.randn_like(p))
+            elif "norm" in n and n.endswith("weight") or n.endswith("cnn.0.2.weight"):
+                p.add_(0.1 * torch.randn_like(p))
+        for s, t in zip(m.encoder.parameters(), m.teacher_encoder.parameters()):
+            t.copy_(s)
+        # perturb the teacher so that student != teacher in the fixture
+        for t in m.teacher_encoder.parameters():
+            t.add_(0.01 * torch.randn_like(t))
+    sd = sd_numpy(m)
+    N = 2
+    audio = torch.randn(N, 1, 32159)
+    ctx = torch.from_numpy(masks["as_ctx"][:N])
+    tgt = torch.from_numpy(masks["as_tgt"][:N])
+    vis = torch.from_numpy(masks["as_vis"][:N])
+    m.train()
+    out = m(audio, ctx, tgt, vis)
+    out["loss"].backward()
+    fx = {f"sd::{k}": v for k, v in sd.items()}
+    fx.update(audio=audio.numpy(), ctx=ctx.numpy(), tgt=tgt.numpy(), vis=vis.numpy())
+    for k in ("local_features", "contextual_features", "preds", "targets", "loss"):
+        fx[f"out::{k}"] = out[k].detach().float().numpy()
+    gn = {}
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            gn[n] = float(p.grad.norm())
+    fx["grad_names"] = np.array(list(gn.keys()))
+    fx["grad_norms"] = np.array(list(gn.values()), dtype=np.float64)
+    fx["grad::extract_audio.cnn.0.0.weight"] = m.extract_audio.cnn[0][0].weight.grad.numpy()
+    fx["grad::encoder.layers.0.self_attn.in_proj_weight"] = m.encoder.layers[0].self_attn.in_proj_weight.grad.numpy()
+    fx["grad::mask_token"] = m.mask_token.grad.numpy()
+    # the stub LightningModule is a plain nn.Module: conv0 input grad check is not needed.
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ob = m(audio.to(torch.bfloat16), ctx, tgt, vis)
+    fx["out_bf16cpu::loss"] = ob["loss"].detach().float().numpy()
+    # inference path
+    pad = torch.zeros(N, 200, dtype=torch.bool)
+    pad[:, 150:] = True
+    rep = m.get_audio_representation(audio, pad)
+    m.train()
+    fx["out::audio_representation"] = rep.detach().numpy()
+    fx["pad_mask"] = pad.numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_model.npz"), **fx)
+    return m, sd, (audio, ctx, tgt, vis)
+
+
+def run_traj(m, batches, steps, warmup, total):
+    trainables = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(trainables, lr=m.hparams.lr, betas=m.hparams.adam_betas, eps=m.hparams.adam_eps,
+                            weight_decay=m.hparams.adam_weight_decay)
+    sch = transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=warmup, num_training_steps=total)
+    losses, gnorms, emas, lrs = [], [], [], []
+    m.global_step = 0
+    m.train()
+    for i in range(steps):
+        b = batches[i % len(batches)]
+        opt.zero_grad()
+        emas.append(m._get_ema_decay())
+        lrs.append(opt.param_groups[0]["lr"])
+        out = m.training_step(b, i)          # forward + EMA (reference jepa.py:318-333)
+        out["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)   # Lightning gradient_clip_val=5, "norm"
+        opt.step()
+        sch.step()
+        m.global_step += 1
+        losses.append(float(out["loss"]))
+        gnorms.append(float(gn))
+    return np.array(losses), np.array(gnorms), np.array(emas), np.array(lrs)
+
+
+def checksums(m):
+    names, sums, abss = [], [], []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        sums.append(float(v.double().sum()))
+        abss.append(float(v.double().abs().sum()))
+    return np.array(names), np.array(sums), np.array(abss)
+
+
+def gen_traj(masks):
+    fx = {}
+    torch.manual_seed(77)
+    batches = []
+    for j in range(3):
+        a = torch.randn(2, 1, 32159)
+        sl = slice(2 * j, 2 * j + 2)
+        batches.append((a, torch.from_numpy(masks["as_ctx"][sl]), torch.from_numpy(masks["as_tgt"][sl]),
+                        torch.from_numpy(masks["as_vis"][sl])))
+    fx["audio"] = np.stack([b[0].numpy() for b in batches])
+    for tag, (warm, total, steps) in dict(short=(3, 20, 12), stock=(100000, 375000, 4)).items():
+        torch.manual_seed(1234)
+        m = build_ref(TINY_SPEC, 64, 4, 2, 32, 4, 2, top_k=2)
+        m.ema_end_step = 100000
+        if tag == "short":
+            fx.update({f"sd0::{k}": v for k, v in sd_numpy(m).items()})
+            # faster EMA so that the teacher visibly moves in 12 steps
+            m.hparams["ema_decay"] = 0.9
+            m.hparams["ema_end_decay"] = 0.99
+            m.ema_end_step = 10
+        l, g, e, lr = run_traj(m, batches, steps, warm, total)
+        n, s, a = checksums(m)
+        fx.update({f"{tag}::loss": l, f"{tag}::gnorm": g, f"{tag}::ema": e, f"{tag}::lr": lr,
+                   f"{tag}::names": n, f"{tag}::sum": s, f"{tag}::abs": a})
+        if tag == "short":
+            fx["short::final::encoder.layers.1.linear1.weight"] = m.encoder.layers[1].linear1.weight.detach().numpy().copy()
+            fx["short::final::teacher_encoder.layers.1.linear1.weight"] = m.teacher_encoder.layers[1].linear1.weight.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "tiny_traj.npz"), **fx)
+
+
+def gen_crops():
+    torch.manual_seed(4321)
+    m = build_ref(TINY_SPEC, 64, 4, 2, 32, 4, 2, top_k=2, seconds=0.25, samples=3)
+    T = m.total_patches
+    B = 2
+    src = torch.randn(B, 1, 9000) * 0.3 + 0.05
+    ctx = torch.zeros(B, 3, T, dtype=torch.bool)
+    tg = torch.zeros(B, 3, 4, T, dtype=torch.bool)
+    torch.manual_seed(99)
+    a, c, t, v = m.on_after_batch_transfer((src, ctx, tg, tg.clone()), 0)
+    # recover the internal random draws by replaying the same generator sequence
+    torch.manual_seed(99)
+    starts = torch.randint(0, 9000 - m.target_length + 1, (B, 3))
+    perm = torch.randperm(B * 3)
+    np.savez_compressed(os.path.join(HERE, "crops.npz"), src=src.numpy(), starts=starts.numpy(), perm=perm.numpy(),
+                        target_length=m.target_length, total_patches=T,
+                        out_bits=a.view(torch.int16).numpy(), out_shape=np.array(a.shape),
+                        ctx_shape=np.array(c.shape), tgt_shape=np.array(t.shape))
+
+
+def gen_base(masks):
+    t0 = time.time()
+    torch.manual_seed(0)
+    m = build_ref(BASE_SPEC, 768, 12, 12, 384, 12, 12, top_k=8)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref_shapes = synth.jepa_shapes(conv_spec=BASE_SPEC, in_channels=1, d_enc=768, enc_layers=12, d_dec=384,
+                                   dec_layers=12, n_tokens=200)
+    assert shapes == ref_shapes, "synth.jepa_shapes drifted from the reference state_dict"
+    sd = synth.synth_state_dict(shapes, seed=7)
+    # teacher slightly different from student
+    for k in list(sd):
+        if k.startswith("teacher_encoder.") and k.endswith("weight") and sd[k].ndim == 2:
+            sd[k] = (sd[k] * np.float32(0.97)).astype(np.float32)
+    own = m.state_dict()
+    for k, v in sd.items():
+        own[k].copy_(torch.from_numpy(v))
+    N = 2
+    audio = torch.from_numpy(synth.synth_audio(N, 1, 32159, seed=3))
+    ctx = torch.from_numpy(masks["as_ctx"][:N])
+    tgt = torch.from_numpy(masks["as_tgt"][:N])
+    vis = torch.from_numpy(masks["as_vis"][:N])
+    m.train()
+    out = m(audio, ctx, tgt, vis)
+    out["loss"].backward()
+    fx = dict(loss=out["loss"].detach().numpy(), n=N, weight_seed=7, audio_seed=3, teacher_scale=0.97)
+    fx["local_features_slice"] = out["local_features"][:, ::25, ::64].detach().numpy()
+    fx["contextual_features_slice"] = out["contextual_features"][::7, ::16].detach().numpy()
+    fx["preds_slice"] = out["preds"][:, ::25, ::64].detach().numpy()
+    fx["targets_slice"] = out["targets"][:, ::25, ::64].detach().numpy()
+    for k in ("local_features", "contextual_features", "preds", "targets"):
+        fx[f"{k}_abs_sum"] = float(out[k].detach().double().abs().sum())
+    groups = {"conv": "extract_audio.", "feature_norms": "feature_norms.", "mapper": "post_extraction_mapper.",
+              "encoder": "encoder.", "enc2dec": "encoder_to_decoder_mapper.", "decoder": "decoder.",
+              "dec2enc": "decoder_to_encoder_mapper.", "mask_token": "mask_token"}
+    gn = {}
+    for g, pre in groups.items():
+        tot = 0.0
+        for n, p in m.named_parameters():
+            if n.startswith(pre) and p.grad is not None:
+                tot += float(p.grad.double().pow(2).sum())
+        gn[g] = tot ** 0.5
+    fx["grad_group_names"] = np.array(list(gn.keys()))
+    fx["grad_group_norms"] = np.array(list(gn.values()))
+    fx["grad_slice::encoder.layers.0.linear1.weight"] = m.encoder.layers[0].linear1.weight.grad[::128, ::64].numpy()
+    fx["grad_slice::extract_audio.cnn.3.0.weight"] = m.extract_audio.cnn[3][0].weight.grad[::64, ::64, :].numpy()
+    fx["grad::extract_audio.cnn.0.0.weight"] = m.extract_audio.cnn[0][0].weight.grad.numpy()
+    fx["n_params_total"] = sum(v.numel() for v in m.state_dict().values())
+    fx["n_params_trainable"] = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    fx["seconds"] = time.time() - t0
+    np.savez_compressed(os.path.join(HERE, "base_forward.npz"), **fx)
+    return m
+
+
+def gen_misc():
+    fx = {}
+    for d in (768, 384, 64):
+        tab = R.pos_embed.get_1d_sincos_pos_embed_from_grid(d, np.arange(200, dtype=np.float64))
+        tab32 = torch.from_numpy(tab).float().numpy()
+        fx[f"pos{d}_slice"] = tab32[::13, ::17]
+        fx[f"pos{d}_sum"] = float(tab32.astype(np.float64).sum())
+        fx[f"pos{d}_row199"] = tab32[199]
+    torch.manual_seed(0)
+    m = build_ref(TINY_SPEC, 64, 4, 2, 32, 4, 2, top_k=2)
+    m.ema_end_step = 100000
+    steps = [0, 1, 50000, 99999, 100000, 200000]
+    dec = []
+    for s in steps:
+        m.global_step = s
+        dec.append(m._get_ema_decay())
+    fx["ema_steps"] = np.array(steps)
+    fx["ema_decay"] = np.array(dec, dtype=np.float64)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=100000, num_training_steps=375000)
+    pts = [0, 1, 1000, 99999, 100000, 100001, 237500, 374999, 375000]
+    fx["lr_steps"] = np.array(pts)
+    fx["lr_lambda"] = np.array([sch.lr_lambdas[0](p) for p in pts], dtype=np.float64)
+    for T_sec, expect in ((2.0, None), (2.01, None), (4.01, None), (4.02, None)):
+        pass
+    ext = R.ConvFeatureExtractor(conv_layers_spec=list(TINY_SPEC), in_channels=1)
+    lens = [16000, 32000, 32159, 32160, 64160, 64320]
+    fx["patch_lens"] = np.array(lens)
+    fx["patch_counts"] = np.array([ext.total_patches(L) for L in lens])
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **fx)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base"]
+    masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
+    if "tiny" in which:
+        gen_tiny(masks)
+    if "traj" in which:
+        gen_traj(masks)
+    if "crops" in which:
+        gen_crops()
+    if "misc" in which:
+        gen_misc()
+    if "base" in which:
+        gen_base(masks)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
