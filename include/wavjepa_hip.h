@@ -1,0 +1,362 @@
+/* libwavjepa_hip.so -- C ABI of the MI355X-native (gfx950) kernels behind the WavJEPA pre-training step.
+ *
+ * The reference (labhamlet/wavjepa) has NO native/FFI boundary: its hot path is stock torch.nn modules called from
+ * wavjepa/jepa.py.  This header is therefore the boundary a maintainer would bind to replace the ATen ops of that
+ * path; each entry cites the reference call site (file:line under /root/reference)
+ * whose computation it replaces.  INTEGRATION.md shows the ctypes stub that binds it from the reference side.
+ *
+ * Conventions
+ *   - every entry:  int wj_xxx(const wj_xxx_args*, void* hip_stream)   -> 0 (WJ_OK) or a negative error code;
+ *     never throws, never allocates, never synchronises; stream-ordered and re-entrant; caller owns all memory.
+ *   - pointers are raw DEVICE pointers; "bf16" = 16-bit brain float, "f32" = IEEE float, "u8" = bool as bytes.
+ *   - activations are token-major ("channels-last"): [rows][features], features contiguous.
+ *   - row counts / leading dimensions are in ELEMENTS.
+ */
+#ifndef WAVJEPA_HIP_H
+#define WAVJEPA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WJ_ABI_VERSION 1
+int wj_abi_version(void);
+/* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
+int wj_device_count(void);
+/* sizeof() of the argument struct named `name` (e.g. "wj_gemm_args"), or -1: lets a binding verify its struct mirror. */
+int wj_struct_size(const char* name);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM (bf16 MFMA, fp32 accumulate) with fused epilogues.
+ * Replaces nn.Linear fwd/bwd everywhere on the path (jepa.py:394,400,439; nn.TransformerEncoderLayer in_proj /
+ * out_proj / linear1 / linear2, types/wavjepa_configs.py:28-47) and nn.Conv1d layers 1..5 as implicit GEMM over the
+ * channels-last activation (extractors/audio_feature_extractor.py:66-70).
+ *   C[M,N] = opA(A) . opB(B);  a_trans=0: A is [M][K] (K contiguous);  a_trans=1: A is stored [K][M] (M contiguous)
+ *                              b_trans=0: B is [N][K] (K contiguous);  b_trans=1: B is stored [K][N] (N contiguous)
+ * Requirements: N%8==0, K%8==0, lda%8==0, ldb%8==0, ldc%4==0; a_trans also needs M%8==0.
+ * -----------------------------------------------------------------------------------------------------------*/
+enum {
+    WJ_EPI_BF16 = 0,          /* C(bf16)  = acc (+ bias[n])                                                  */
+    WJ_EPI_BIAS_GELU2 = 1,    /* C(bf16)  = h = acc + bias ;  C2(bf16) = gelu(h)   (linear1 + nn.GELU)         */
+    WJ_EPI_MUL_GELU_GRAD = 2, /* C(bf16)  = bf16(acc) * gelu'(aux(bf16))           (backward through GELU)     */
+    WJ_EPI_ADD_F32 = 3,       /* C(f32)   = acc (+ aux(f32))                       (dgrad + residual-stream)   */
+    WJ_EPI_ATOMIC_F32 = 4,    /* C(f32)  += alpha * acc   (atomic; split_k >= 1)   (wgrad into the grad buffer) */
+    WJ_EPI_CONV_GELU = 5      /* C(bf16)  = pre = bf16(acc); C2(bf16) = gelu(pre); rows (m % seg_rows) >= seg_valid -> 0 */
+};
+typedef struct {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;
+    const void* bias; /* f32 [N] or NULL */
+    const void* aux;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t a_trans, b_trans;
+    int32_t epilogue;
+    int32_t split_k;
+    int32_t seg_rows, seg_valid;
+    float alpha;
+} wj_gemm_args;
+int wj_gemm_bf16(const wj_gemm_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LayerNorm (fp32 statistics), optionally fused with the post-norm residual add.
+ * Replaces nn.LayerNorm at jepa.py:392 (feature_norms) and norm1/norm2/final norm of every transformer layer
+ * (x = norm(x + branch), torch TransformerEncoderLayer post-norm branch).
+ *   s = x (+ r);  y = (s - mean) * rstd * gamma + beta
+ *   x: f32, or bf16 when x_is_bf16;  r: bf16 or NULL;  outputs y_f32 / y_bf16 / mean / rstd are each optional.
+ *   Input row m is read at row (m / in_valid) * in_seg + (m % in_valid) when in_seg > 0 (padded conv token buffer).
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const void* x;
+    const void* r;
+    const float* gamma;
+    const float* beta;
+    float* y_f32;
+    void* y_bf16;
+    float* mean;
+    float* rstd;
+    int32_t M, D;
+    int32_t x_is_bf16;
+    int32_t in_seg, in_valid;
+    float eps;
+} wj_ln_fwd_args;
+int wj_layernorm_fwd(const wj_ln_fwd_args*, void* stream);
+
+/* Backward of the above.  ds = d(x + r) = LN-backward(dy);  dgamma/dbeta (and dbias = column sums of bf16(ds), the
+ * bias gradient of the Linear that produced r) are ACCUMULATED with atomics into f32 buffers.
+ *   dy: f32 [M][D] (+ optional second addend dy2 f32);  outputs ds_f32 / ds_bf16 optional;
+ *   ds_bf16 row m is written at row (m / out_valid) * out_seg + (m % out_valid) when out_seg > 0. */
+typedef struct {
+    const float* dy;
+    const float* dy2;
+    const void* x;
+    const void* r;
+    const float* gamma;
+    const float* mean;
+    const float* rstd;
+    float* ds_f32;
+    void* ds_bf16;
+    float* dgamma;
+    float* dbeta;
+    float* dbias;
+    int32_t M, D;
+    int32_t x_is_bf16;
+    int32_t in_seg, in_valid;
+    int32_t out_seg, out_valid;
+} wj_ln_bwd_args;
+int wj_layernorm_bwd(const wj_ln_bwd_args*, void* stream);
+
+/* out[n] += sum_m bf16 X[m][n]   (bias gradients of in_proj / linear1 / mappers; atomic accumulate) */
+typedef struct {
+    const void* x;
+    float* out;
+    int64_t ldx;
+    int32_t M, N;
+} wj_colsum_args;
+int wj_colsum_bf16(const wj_colsum_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-head self-attention with a key-padding mask, forward and backward.
+ * Replaces F.multi_head_attention_forward / scaled_dot_product_attention inside nn.TransformerEncoderLayer for the
+ * student (jepa.py:397,452, mask = ctx_masks), the predictor (jepa.py:438, mask = ctx_and_target_masks) and the
+ * teacher (jepa.py:256-258, no mask).   qkv: bf16 [B][T][3*H*hd] packed q|k|v;  key_mask: u8 [B][T], nonzero =
+ * key NOT attended, or NULL;  out: bf16 [B][T][H*hd];  lse: f32 [B][H][T] (log-sum-exp of scaled scores).
+ * hd in {32, 64};  T <= 224.
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const void* qkv;
+    const uint8_t* key_mask;
+    void* out;
+    float* lse;
+    int32_t B, T, H, hd;
+    int32_t mask_group; /* mask row used for batch b is b / mask_group (>=1); lets [B,T] masks serve B*G batches */
+} wj_attn_fwd_args;
+int wj_attn_fwd(const wj_attn_fwd_args*, void* stream);
+
+typedef struct {
+    const void* qkv;
+    const uint8_t* key_mask;
+    const void* out;
+    const void* dout; /* bf16 [B][T][H*hd] */
+    const float* lse;
+    void* dqkv;       /* bf16 [B][T][3*H*hd] */
+    int32_t B, T, H, hd;
+    int32_t mask_group;
+} wj_attn_bwd_args;
+int wj_attn_bwd(const wj_attn_bwd_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Conv layer 0 (C_in x k x stride, no bias) + GroupNorm(C, C) + erf-GELU, channels-last output.
+ * Replaces cnn[0] = Conv1d -> Dropout(0) -> GroupNorm(dim, dim) -> GELU (audio_feature_extractor.py:90-96).
+ *   audio: bf16 [N][C_in][L];  w: bf16 [C][C_in][k];  gamma/beta: f32 [C];
+ *   act: bf16 [N][P][C] (rows >= L_out of every clip are written as 0);  mean/rstd: f32 [N][C] (of the bf16-rounded
+ *   conv output over time, biased variance, eps 1e-5).
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const void* audio;
+    const void* w;
+    const float* gamma;
+    const float* beta;
+    void* act;
+    float* mean;
+    float* rstd;
+    float* workspace; /* f32 [N][C][2] scratch (sum, sum of squares) */
+    int32_t N, C_in, L, C, k, stride, L_out, P;
+    float eps;
+} wj_conv0_fwd_args;
+int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args*, void* stream);
+
+/* Backward: dact bf16 [N][P][C] -> dw f32 [C][C_in][k], dgamma, dbeta (all atomically accumulated).
+ * workspace: f32 [N][C][2]. */
+typedef struct {
+    const void* audio;
+    const void* w;
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* rstd;
+    const void* dact;
+    float* dw;
+    float* dgamma;
+    float* dbeta;
+    float* workspace;
+    int32_t N, C_in, L, C, k, stride, L_out, P;
+} wj_conv0_bwd_args;
+int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args*, void* stream);
+
+/* dpre(bf16) = dpost(bf16) * gelu'(pre(bf16)), elementwise over n elements (conv layers 1..5 backward through GELU;
+ * rows that are padding hold pre = 0, dpost = 0 and stay 0). */
+typedef struct {
+    const void* dpost;
+    const void* pre;
+    void* dpre;
+    int64_t n;
+} wj_gelu_bwd_args;
+int wj_gelu_bwd_bf16(const wj_gelu_bwd_args*, void* stream);
+
+/* Conv weight layout helpers (reference layout [C_out][C_in][k] f32  <->  GEMM layouts, bf16).
+ *   mode 0: wp[o][kk*C_in + c]            = w[o][c][kk]                       (forward, B row form, K = k*C_in)
+ *   mode 1: wd[(v*C_out + o)][c]          = w[o][c][rho + stride*(U-1-v)]     (dgrad phase rho, U taps, B col form)
+ *   mode 2: dw[o][c][kk] += dwp[o][kk*C_in + c]   (f32 -> f32, un-permute the wgrad into the parameter gradient) */
+typedef struct {
+    const void* src;
+    void* dst;
+    int32_t C_out, C_in, k, stride, rho, U, mode;
+} wj_conv_w_args;
+int wj_conv_weight_layout(const wj_conv_w_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Token plumbing.
+ * -----------------------------------------------------------------------------------------------------------*/
+/* y_f32[m][d] = f32(x_bf16[m][d]) + pos[(m % T)][d];  y_bf16 = bf16(y_f32)          (jepa.py:396) */
+typedef struct {
+    const void* x;
+    const float* pos;
+    float* y_f32;
+    void* y_bf16;
+    int32_t M, T, D;
+} wj_add_pos_args;
+int wj_add_pos(const wj_add_pos_args*, void* stream);
+
+/* Boolean-mask row gather:  out[j] = x[idx[j]] for j < n_rows (idx = flat (b*T+t) of rows with ~ctx_mask, ascending).
+ * Pure copy, bit-exact (jepa.py:399).  elem_bytes in {2,4}.  Also the backward of the scatter below. */
+typedef struct {
+    const void* x;
+    const int32_t* idx;
+    void* out;
+    int32_t n_rows, D, elem_bytes;
+} wj_gather_args;
+int wj_mask_gather_rows(const wj_gather_args*, void* stream);
+
+/* Predictor input (jepa.py:425-435):  for group g, row (b,t):
+ *   tok = inv[b*T+t] >= 0 ? ctx_feats[inv[b*T+t]] : mask_token        (bf16)
+ *   out_f32[(b*G+g)][t] = f32(tok) + pos[t];  out_bf16 = bf16(out_f32) */
+typedef struct {
+    const void* ctx_feats;   /* bf16 [n_ctx][D] */
+    const int32_t* inv;      /* [B*T]: position in ctx_feats or -1 */
+    const float* mask_token; /* f32 [D] */
+    const float* pos;        /* f32 [T][D] */
+    float* out_f32;
+    void* out_bf16;
+    int32_t B, T, D, G;
+} wj_scatter_fill_args;
+int wj_mask_scatter_fill_pos(const wj_scatter_fill_args*, void* stream);
+
+/* Backward of the above: dtok[b*T+t] = sum_g d_in[(b*G+g)][t] (f32);  rows with inv >= 0 go to d_ctx_feats (bf16),
+ * the others are summed into d_mask_token (f32, atomic). */
+typedef struct {
+    const float* d_in;
+    const int32_t* inv;
+    void* d_ctx_feats;
+    float* d_mask_token;
+    int32_t B, T, D, G;
+} wj_scatter_fill_bwd_args;
+int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args*, void* stream);
+
+/* dst_f32[m][:] = inv[m] >= 0 ? f32(src_bf16[inv[m]][:]) : 0   for all M rows (dgrad of the gather: the gradient
+ * w.r.t. the student encoder output is zero on non-context rows, jepa.py:399). */
+typedef struct {
+    const void* src;
+    const int32_t* inv;
+    float* dst;
+    int32_t M, D;
+} wj_unmask_rows_args;
+int wj_unmask_rows_f32(const wj_unmask_rows_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Teacher targets and loss.
+ * -----------------------------------------------------------------------------------------------------------*/
+/* targets[b] (+)= ((x[b] - mean_b) * rsqrt(var_b + eps)) * scale,  statistics JOINT over the T*D elements of sample b
+ * (F.instance_norm on the reference's 4-D stack, jepa.py:244-252).  accumulate = 0 overwrites. */
+typedef struct {
+    const float* x;
+    float* targets;
+    int32_t B, TD;
+    int32_t accumulate;
+    float scale, eps;
+} wj_instnorm_args;
+int wj_instnorm_accumulate(const wj_instnorm_args*, void* stream);
+
+/* Masked MSE (jepa.py:335-362).  preds bf16 [B*G][T][D], targets f32 [B][T][D], tgt u8 [B][G][T].
+ *   loss[0] = sum_{tgt} mean_d (p - y)^2 / (count + 1e-8);  loss[1] = count.
+ *   If dpreds != NULL also writes dpreds (bf16) = tgt ? 2 (p - y) / (D (count + 1e-8)) * gscale : 0.
+ * workspace: f32 [2 + B*G*T]. */
+typedef struct {
+    const void* preds;
+    const float* targets;
+    const uint8_t* tgt;
+    float* loss;
+    void* dpreds;
+    float* workspace;
+    int32_t B, G, T, D;
+    float gscale;
+} wj_mse_args;
+int wj_masked_mse(const wj_mse_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser-side fused kernels over FLAT parameter storage.
+ * -----------------------------------------------------------------------------------------------------------*/
+/* teacher = r * teacher + (1 - r) * student (f32, jepa.py:193-198); also refreshes teacher_bf16 when non-NULL. */
+typedef struct {
+    const float* student;
+    float* teacher;
+    void* teacher_bf16;
+    int64_t n;
+    float r;
+} wj_ema_args;
+int wj_ema_update(const wj_ema_args*, void* stream);
+
+/* out[0] = sum of squares of g[0..n) (f32).  workspace f32 [1024].  (torch clip_grad_norm_, train.py:177-178) */
+typedef struct {
+    const float* g;
+    float* out;
+    float* workspace;
+    int64_t n;
+} wj_sumsq_args;
+int wj_grad_sumsq(const wj_sumsq_args*, void* stream);
+
+/* AdamW with fused global-norm clipping (torch.optim.AdamW as configured at jepa.py:215-228 + gradient_clip_val=5):
+ *   c = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6));  g = c * grad * grad_scale;
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+ * Also refreshes the bf16 shadow copy of p when p_bf16 != NULL.  max_norm <= 0 disables clipping. */
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    void* p_bf16;
+    const float* sumsq;
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, grad_scale;
+} wj_adamw_args;
+int wj_adamw_step(const wj_adamw_args*, void* stream);
+
+/* dst_bf16[i] = bf16(src_f32[i]) */
+typedef struct {
+    const float* src;
+    void* dst;
+    int64_t n;
+} wj_cast_args;
+int wj_cast_f32_to_bf16(const wj_cast_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Batch preparation (jepa.py:291-316): crop `length` samples at starts[b][s] of source row b, normalise by the
+ * crop's own mean / UNBIASED std over (C, length): (x - mean) / (std + 1e-5), cast to bf16, write at output row
+ * perm_inv[b*S+s] (or b*S+s when perm_inv is NULL).   src f32 [B][C][L_full] -> out bf16 [B*S][C][length]
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const float* src;
+    const int32_t* starts;
+    const int32_t* perm_inv;
+    void* out;
+    int32_t B, S, C, L_full, length;
+} wj_crop_args;
+int wj_crop_normalize_bf16(const wj_crop_args*, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVJEPA_HIP_H */

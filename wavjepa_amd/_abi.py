@@ -1,0 +1,125 @@
+"""ctypes binding of libwavjepa_hip.so.
+
+The argument structs are generated from `include/wavjepa_hip.h` itself (a tiny parser for its plain-C struct
+syntax), so the Python mirror cannot drift from the header; sizes are cross-checked against the library's own
+`wj_struct_size`.  There is NO fallback: if the shared library is missing or a symbol is absent, importing the
+product path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip.h")
+LIB_PATH = os.path.join(HERE, "lib", "libwavjepa_hip.so")
+
+_SCALARS = {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "int": ctypes.c_int}
+
+
+class WavJepaHipError(RuntimeError):
+    pass
+
+
+def _strip_comments(text: str) -> str:
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def parse_header(path: str = HEADER) -> Tuple[Dict[str, List[Tuple[str, object]]], List[str], Dict[str, int]]:
+    """Returns ({struct name: [(field, ctype)]}, [function names], {enum constant: value})."""
+    text = _strip_comments(open(path).read())
+    structs: Dict[str, List[Tuple[str, object]]] = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields: List[Tuple[str, object]] = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            is_ptr = "*" in decl
+            toks = decl.replace("*", " * ").split()
+            toks = [t for t in toks if t != "const"]
+            base = toks[0]
+            names = "".join(toks[1:]).replace("*", "").split(",")
+            for n in names:
+                n = n.strip()
+                if not n:
+                    continue
+                fields.append((n, ctypes.c_void_p if is_ptr else _SCALARS[base]))
+        structs[name] = fields
+    funcs = re.findall(r"\bint\s+(wj_\w+)\s*\(", text)
+    enums: Dict[str, int] = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}\s*;", text, flags=re.S):
+        val = -1
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                k, v = item.split("=")
+                val = int(v.strip(), 0)
+                enums[k.strip()] = val
+            else:
+                val += 1
+                enums[item] = val
+    return structs, funcs, enums
+
+
+_STRUCT_FIELDS, FUNCTIONS, ENUMS = parse_header()
+
+
+def _make_struct(name: str, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": fields})
+
+
+STRUCTS = {name: _make_struct(name, fields) for name, fields in _STRUCT_FIELDS.items()}
+_NO_STREAM_FUNCS = {"wj_abi_version": [], "wj_device_count": [], "wj_struct_size": [ctypes.c_char_p]}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once).  Raises WavJepaHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WavJepaHipError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m wavjepa_amd.build` "
+            "(or __graft_entry__.build()). wavjepa_amd has no CPU/PyTorch fallback by design.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise WavJepaHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for fn in FUNCTIONS:
+        if not hasattr(lib, fn):
+            raise WavJepaHipError(f"{LIB_PATH} does not export {fn} (declared in include/wavjepa_hip.h); rebuild it")
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_int
+        if fn in _NO_STREAM_FUNCS:
+            f.argtypes = _NO_STREAM_FUNCS[fn]
+        else:
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    if lib.wj_abi_version() != ENUMS.get("WJ_ABI_VERSION", lib.wj_abi_version()):
+        pass
+    for name, cls in STRUCTS.items():
+        want = lib.wj_struct_size(name.encode())
+        if want != ctypes.sizeof(cls):
+            raise WavJepaHipError(f"struct {name}: header mirror is {ctypes.sizeof(cls)} bytes, library says {want}")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+
+
+def call(fn_name: str, args_struct, stream: int) -> None:
+    rc = getattr(load(), fn_name)(ctypes.byref(args_struct), stream)
+    if rc != 0:
+        raise WavJepaHipError(f"{fn_name} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,376 @@
+// Key-masked multi-head self-attention for short sequences (T <= 224, head dim 32/64) on gfx950.
+//
+// One workgroup (4 waves) per (batch, head).  The whole K/V (forward) or K,V then Q,dO (backward) of that head
+// lives in LDS as ONE padded image per matrix ([rows][hd*2+32 bytes]) that serves both the row reads
+// (ds_read_b128 -> MFMA operand with k = head dim) and the transposed reads (ds_read_b64_tr_b16 -> MFMA operand
+// with k = sequence), conflict-free for both.  Scores are computed TRANSPOSED (S^T = K Q^T) so that the softmax
+// reduction runs over registers + two cross-lane shuffles, and the fp32 accumulator tile is converted in place
+// to the bf16 B-operand of the following MFMA (O^T = V^T P^T): P never goes through LDS.
+//   forward : S^T -> mask/softmax -> O^T, LSE
+//   backward: phase A (per query tile)  dQ^T = K^T dS^T        with S^T, dP^T = V dO^T recomputed
+//             phase B (per key tile)    dV^T = dO^T P, dK^T = Q^T dS   with S = Q K^T, dP = dO V^T recomputed
+#include "common.h"
+#include "../../include/wavjepa_hip.h"
+
+namespace {
+
+constexpr int MAX_TILES = 14;  // 16-row tiles: T <= 224
+constexpr int NW = 4;          // waves per workgroup
+
+template <int HD> struct Img {
+    static constexpr int RS = HD * 2 + 32;  // padded row stride in bytes
+    static constexpr int CH = HD / 8;       // 16-B chunks per row
+};
+
+// Copy rows [0,T) of a [T][ld] bf16 matrix (HD columns) into the padded LDS image; rows [T,KP) are zero.
+template <int HD>
+__device__ __forceinline__ void fill_image(char* img, const bf16_t* __restrict__ src, long ld, int T, int KP) {
+    constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
+    for (int idx = threadIdx.x; idx < KP * CH; idx += blockDim.x) {
+        const int row = idx / CH, c = idx - row * CH;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < T) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + c * 8);
+        *reinterpret_cast<uint4*>(img + row * RS + c * 16) = v;
+    }
+}
+
+// MFMA operand with k = head-dim: lane (i,g) gets row (rbase+i), d = ks*32 + 8g .. +7, from the LDS image.
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int rbase, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(img + (rbase + i) * Img<HD>::RS + (ks * 4 + g) * 16);
+}
+// Same operand straight from global memory (each wave needs its own 16 rows exactly once).
+__device__ __forceinline__ bf16x8 row_frag_global(const bf16_t* __restrict__ src, long ld, int rbase, int T, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int row = rbase + i;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = f2bf(0.f);
+    if (row < T) z = *reinterpret_cast<const bf16x8*>(src + (long)row * ld + ks * 32 + 8 * g);
+    return z;
+}
+// MFMA A-operand with k = sequence (32-row chunk c) and rows = head-dim slice [d0, d0+16), matched to a B operand
+// built from two accumulator tiles: element j of lane group g is sequence row c*32 + (j<4 ? 4g+j : 16+4g+j-4).
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int c, int d0, int lane) {
+    const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+    const char* a0 = img + (c * 32 + 4 * g + q) * Img<HD>::RS + ((d0 + 4 * p) << 1);
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0 + 16 * Img<HD>::RS));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ bf16x8 pack_tiles(f32x4 lo, f32x4 hi) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = f2bf(lo[e]); r[4 + e] = f2bf(hi[e]); }
+    return r;
+}
+__device__ __forceinline__ float group_max(float v) {  // over the 4 lane groups (same lane&15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int HD>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a) {
+    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = a.T, H = a.H, D = H * HD;
+    const int nkt = (T + 15) / 16, KP = ((T + 31) / 32) * 32, nch = KP / 32;
+    char* kimg = smem;
+    char* vimg = smem + KP * RS;
+    float* madd = reinterpret_cast<float*>(smem + 2 * KP * RS);
+
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const long ld = 3L * D;
+    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * T * ld + h * HD;
+    fill_image<HD>(kimg, base + D, ld, T, KP);
+    fill_image<HD>(vimg, base + 2 * D, ld, T, KP);
+    const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
+    for (int k = threadIdx.x; k < KP; k += blockDim.x)
+        madd[k] = (k < T && !(km && km[k])) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const float scale = rsqrtf((float)HD);
+    for (int qt = wave; qt < nkt; qt += NW) {
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, qt * 16, T, ks, lane);
+        f32x4 s[MAX_TILES];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MAX_TILES; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(kimg, kt * 16, ks, lane), qf[ks], s[kt], 0, 0, 0);
+                const f32x4 ma = *reinterpret_cast<const f32x4*>(madd + kt * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = s[kt][r] * scale + ma[r];
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            }
+        }
+        mx = group_max(mx);
+        const float msafe = (mx == -INFINITY) ? 0.f : mx;  // fully masked row: all p = 0 (the reference yields NaN)
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MAX_TILES; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[kt][r] - msafe);
+                    s[kt][r] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum = group_sum(sum);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < MAX_TILES / 2; ++c) {
+            if (c < nch) {
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                // probabilities are normalised BEFORE the bf16 rounding (as a materialised softmax would be)
+                const bf16x8 pf = pack_tiles(s[2 * c] * inv, (2 * c + 1 < nkt) ? s[2 * c + 1] * inv : z);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(vimg, c, dt * 16, lane), pf, o[dt], 0, 0, 0);
+            }
+        }
+        const int q = qt * 16 + i;
+        if (q < T) {
+            bf16_t* op = (bf16_t*)a.out + ((long)b * T + q) * D + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = f2bf(o[dt][r]);
+                *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) = ov;
+            }
+            if (a.lse && g == 0) a.lse[((long)b * H + h) * T + q] = sum > 0.f ? msafe + __logf(sum) : INFINITY;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int HD>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a) {
+    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = a.T, H = a.H, D = H * HD;
+    const int nt = (T + 15) / 16, KP = ((T + 31) / 32) * 32, nch = KP / 32;
+    char* img0 = smem;                // phase A: K      phase B: Q
+    char* img1 = smem + KP * RS;      // phase A: V      phase B: dO
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * KP * RS);  // [KP]  (+inf for rows >= T)
+    float* delta = lse_s + KP;                                     // [KP]
+    float* kvalid = delta + KP;                                    // [KP]  1 = key attended, 0 = masked / padding
+
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const long ld = 3L * D;
+    const bf16_t* qkv = (const bf16_t*)a.qkv + (long)b * T * ld + h * HD;
+    const bf16_t* dO = (const bf16_t*)a.dout + (long)b * T * D + h * HD;
+    const bf16_t* O = (const bf16_t*)a.out + (long)b * T * D + h * HD;
+    bf16_t* dqkv = (bf16_t*)a.dqkv + (long)b * T * ld + h * HD;
+    const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
+
+    fill_image<HD>(img0, qkv + D, ld, T, KP);
+    fill_image<HD>(img1, qkv + 2 * D, ld, T, KP);
+    for (int r = threadIdx.x; r < KP; r += blockDim.x) {
+        float l = INFINITY, dl = 0.f, kv = 0.f;
+        if (r < T) {
+            l = a.lse[((long)b * H + h) * T + r];
+            kv = (km && km[r]) ? 0.f : 1.f;
+#pragma unroll
+            for (int c = 0; c < HD / 8; ++c) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (long)r * D + c * 8);
+                const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (long)r * D + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += bf2f(x[e]) * bf2f(y[e]);
+            }
+        }
+        lse_s[r] = l; delta[r] = dl; kvalid[r] = kv;
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)HD);
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- phase A: dQ for 16 queries per wave iteration (queries on the lane, keys on the accumulator rows)
+    for (int qt = wave; qt < nt; qt += NW) {
+        bf16x8 qf[KS], dof[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = row_frag_global(qkv, ld, qt * 16, T, ks, lane);
+            dof[ks] = row_frag_global(dO, D, qt * 16, T, ks, lane);
+        }
+        const float my_lse = lse_s[qt * 16 + i], my_delta = delta[qt * 16 + i];
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = zero4;
+#pragma unroll
+        for (int c = 0; c < MAX_TILES / 2; ++c) {
+            if (c < nch) {
+                f32x4 ds2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kt = 2 * c + u;
+                    ds2[u] = zero4;
+                    if (kt < nt) {
+                        f32x4 s = zero4, dp = zero4;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img0, kt * 16, ks, lane), qf[ks], s, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img1, kt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
+                        }
+                        const f32x4 kv = *reinterpret_cast<const f32x4*>(kvalid + kt * 16 + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = kv[r] * __expf(s[r] * scale - my_lse);
+                            ds2[u][r] = p * (dp[r] - my_delta) * scale;
+                        }
+                    }
+                }
+                const bf16x8 dsf = pack_tiles(ds2[0], ds2[1]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img0, c, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        const int q = qt * 16 + i;
+        if (q < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = f2bf(dq[dt][r]);
+                *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+    __syncthreads();
+    fill_image<HD>(img0, qkv, ld, T, KP);
+    fill_image<HD>(img1, dO, D, T, KP);
+    __syncthreads();
+
+    // ---- phase B: dK, dV for 16 keys per wave iteration (keys on the lane, queries on the accumulator rows)
+    for (int kt = wave; kt < nt; kt += NW) {
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = row_frag_global(qkv + D, ld, kt * 16, T, ks, lane);
+            vf[ks] = row_frag_global(qkv + 2 * D, ld, kt * 16, T, ks, lane);
+        }
+        const float my_kv = kvalid[kt * 16 + i];
+        f32x4 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = zero4;
+#pragma unroll
+        for (int c = 0; c < MAX_TILES / 2; ++c) {
+            if (c < nch) {
+                f32x4 p2[2], ds2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qt = 2 * c + u;
+                    p2[u] = ds2[u] = zero4;
+                    if (qt < nt) {
+                        f32x4 s = zero4, dp = zero4;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img0, qt * 16, ks, lane), kf[ks], s, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img1, qt * 16, ks, lane), vf[ks], dp, 0, 0, 0);
+                        }
+                        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
+                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + qt * 16 + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = my_kv * __expf(s[r] * scale - l4[r]);
+                            p2[u][r] = p;
+                            ds2[u][r] = p * (dp[r] - d4[r]) * scale;
+                        }
+                    }
+                }
+                const bf16x8 pf = pack_tiles(p2[0], p2[1]);
+                const bf16x8 dsf = pack_tiles(ds2[0], ds2[1]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img1, c, dt * 16, lane), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img0, c, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        const int key = kt * 16 + i;
+        if (key < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 ok, ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dk[dt][r]); ov[r] = f2bf(dv[dt][r]); }
+                *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
+                *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
+            }
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kern, int bytes) {
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
+    if (!a || !a->qkv || !a->out) return WJ_ERR_ARG;
+    if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
+    if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    const int KP = ((a->T + 31) / 32) * 32;
+    const int lds = 2 * KP * (a->hd * 2 + 32) + KP * 4;
+    dim3 grid(a->B * a->H), block(NW * 64);
+    if (a->hd == 64) {
+        static int once = set_lds(attn_fwd_kernel<64>, 2 * 224 * 160 + 224 * 4);
+        (void)once;
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, lds, (hipStream_t)stream, *a);
+    } else {
+        static int once = set_lds(attn_fwd_kernel<32>, 2 * 224 * 96 + 224 * 4);
+        (void)once;
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, lds, (hipStream_t)stream, *a);
+    }
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
+    if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->dqkv) return WJ_ERR_ARG;
+    if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
+    if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    const int KP = ((a->T + 31) / 32) * 32;
+    const int lds = 2 * KP * (a->hd * 2 + 32) + 3 * KP * 4;
+    dim3 grid(a->B * a->H), block(NW * 64);
+    if (a->hd == 64) {
+        static int once = set_lds(attn_bwd_kernel<64>, 2 * 224 * 160 + 3 * 224 * 4);
+        (void)once;
+        hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, lds, (hipStream_t)stream, *a);
+    } else {
+        static int once = set_lds(attn_bwd_kernel<32>, 2 * 224 * 96 + 3 * 224 * 4);
+        (void)once;
+        hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, lds, (hipStream_t)stream, *a);
+    }
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}

@@ -1,0 +1,326 @@
+// Conv layer 0 (C_in*k taps, stride s, no bias) + GroupNorm(C, C) + erf-GELU, forward and backward, gfx950.
+// C_in*k is tiny (10 taps for mono audio), so this is not a GEMM shape: it is an HBM-bound producer of the
+// [N][P][C] channels-last bf16 activation (1.69 GB at N=256), written exactly once.  The conv is recomputed from
+// the audio wherever it is needed (statistics pass, apply pass, both backward passes) instead of being stored.
+//   thread = 4 consecutive channels x one time parity;  a wave stores 512 contiguous bytes per time step.
+#include "common.h"
+#include "../../include/wavjepa_hip.h"
+
+namespace {
+
+constexpr int TC = 256;   // output time steps per workgroup
+constexpr int NTH = 256;  // threads
+
+struct Geo {
+    int N, C_in, L, C, k, stride, L_out, P;
+};
+
+template <int TAPS>
+__device__ __forceinline__ void load_weights(float (&w)[4][TAPS], const bf16_t* __restrict__ wsrc, int c4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) w[j][tp] = bf2f(wsrc[(long)(c4 + j) * TAPS + tp]);
+}
+
+// audio chunk for output steps [t0, t0+TC): xs[ci][i] = audio[n][ci][t0*stride + i], i < span
+__device__ __forceinline__ int stage_audio(float* xs, const bf16_t* __restrict__ audio, const Geo& g, int n, int t0, int span_max) {
+    const int span = min(span_max, g.L - t0 * g.stride);
+    for (int ci = 0; ci < g.C_in; ++ci)
+        for (int i = threadIdx.x; i < span_max; i += NTH)
+            xs[ci * span_max + i] = i < span ? bf2f(audio[((long)n * g.C_in + ci) * g.L + (long)t0 * g.stride + i]) : 0.f;
+    return span;
+}
+
+template <int TAPS>
+__device__ __forceinline__ void tap_offsets(int (&off)[TAPS], const Geo& g, int span_max) {
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+        const int ci = tp / g.k, kk = tp - ci * g.k;
+        off[tp] = ci * span_max + kk;
+    }
+}
+
+template <int TAPS>
+__device__ __forceinline__ void conv4(float (&y)[4], float (&x)[TAPS], const float (&w)[4][TAPS], const float* xs,
+                                      const int (&off)[TAPS], int tl, int stride) {
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) x[tp] = xs[off[tp] + tl * stride];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) a = fmaf(x[tp], w[j][tp], a);
+        y[j] = bf2f(f2bf(a));  // the conv output is a bf16 tensor in the reference's autocast flow
+    }
+}
+
+// ---- pass 1 (forward): per-(n,c) sum and sum of squares of the bf16-rounded conv output -------------------
+template <int TAPS>
+__global__ __launch_bounds__(NTH) void conv0_stats_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                          float* __restrict__ sums, Geo g, int span_max) {
+    extern __shared__ float xs[];
+    const int n = blockIdx.y, t0 = blockIdx.x * TC;
+    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
+    stage_audio(xs, audio, g, n, t0, span_max);
+    __syncthreads();
+    const int tmax = min(TC, g.L_out - t0);
+    for (int cb = 0; cb < g.C; cb += 512) {
+        const int c4 = cb + cl * 4;
+        if (c4 < g.C) {
+            float w[4][TAPS];
+            load_weights<TAPS>(w, wsrc, c4);
+            float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+            int off[TAPS];
+            tap_offsets<TAPS>(off, g, span_max);
+            for (int tl = half; tl < tmax; tl += 2) {
+                float y[4], x[TAPS];
+                conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += y[j]; s2[j] += y[j] * y[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(sums + ((long)n * g.C + c4 + j) * 2 + 0, s1[j]);
+                atomicAdd(sums + ((long)n * g.C + c4 + j) * 2 + 1, s2[j]);
+            }
+        }
+    }
+}
+
+// ---- pass 2 (forward): normalise, GELU, write channels-last bf16; emit mean / rstd ---------------------------
+template <int TAPS>
+__global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ sums, bf16_t* __restrict__ act,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o, Geo g,
+                                                          int span_max, float eps) {
+    extern __shared__ float xs[];
+    const int n = blockIdx.y, t0 = blockIdx.x * TC;
+    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
+    stage_audio(xs, audio, g, n, t0, span_max);
+    __syncthreads();
+    const int tmax = min(TC, g.P - t0);
+    const float invL = 1.0f / (float)g.L_out;
+    for (int cb = 0; cb < g.C; cb += 512) {
+        const int c4 = cb + cl * 4;
+        if (c4 >= g.C) continue;
+        float w[4][TAPS];
+        load_weights<TAPS>(w, wsrc, c4);
+        float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s1 = sums[((long)n * g.C + c4 + j) * 2], s2 = sums[((long)n * g.C + c4 + j) * 2 + 1];
+            mu[j] = s1 * invL;
+            const float var = fmaxf(s2 * invL - mu[j] * mu[j], 0.f);
+            rs[j] = rsqrtf(var + eps);
+            ga[j] = gamma[c4 + j];
+            be[j] = beta[c4 + j];
+            if (blockIdx.x == 0 && half == 0) {
+                mean_o[(long)n * g.C + c4 + j] = mu[j];
+                rstd_o[(long)n * g.C + c4 + j] = rs[j];
+            }
+        }
+        int off[TAPS];
+        tap_offsets<TAPS>(off, g, span_max);
+        for (int tl = half; tl < tmax; tl += 2) {
+            const int t = t0 + tl;
+            bf16x4 o;
+            if (t < g.L_out) {
+                float y[4], x[TAPS];
+                conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(gelu_f((y[j] - mu[j]) * rs[j] * ga[j] + be[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = f2bf(0.f);
+            }
+            *reinterpret_cast<bf16x4*>(act + ((long)n * g.P + t) * g.C + c4) = o;
+        }
+    }
+}
+
+// ---- backward pass 1: A1 = sum_t dz, A2 = sum_t dz * xhat per (n,c) ----------------------------------------------
+template <int TAPS>
+__global__ __launch_bounds__(NTH) void conv0_bwd_stats_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const bf16_t* __restrict__ dact, float* __restrict__ ws, Geo g,
+                                                              int span_max) {
+    extern __shared__ float xs[];
+    const int n = blockIdx.y, t0 = blockIdx.x * TC;
+    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
+    stage_audio(xs, audio, g, n, t0, span_max);
+    __syncthreads();
+    const int tmax = min(TC, g.L_out - t0);
+    for (int cb = 0; cb < g.C; cb += 512) {
+        const int c4 = cb + cl * 4;
+        if (c4 >= g.C) continue;
+        float w[4][TAPS];
+        load_weights<TAPS>(w, wsrc, c4);
+        float mu[4], rs[4], ga[4], be[4], a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mu[j] = mean[(long)n * g.C + c4 + j]; rs[j] = rstd[(long)n * g.C + c4 + j];
+            ga[j] = gamma[c4 + j]; be[j] = beta[c4 + j];
+        }
+        int off[TAPS];
+        tap_offsets<TAPS>(off, g, span_max);
+        for (int tl = half; tl < tmax; tl += 2) {
+            const int t = t0 + tl;
+            float y[4], x[TAPS];
+            conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
+            const bf16x4 d = *reinterpret_cast<const bf16x4*>(dact + ((long)n * g.P + t) * g.C + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (y[j] - mu[j]) * rs[j];
+                const float dz = bf2f(d[j]) * gelu_grad_f(xh * ga[j] + be[j]);
+                a1[j] += dz;
+                a2[j] += dz * xh;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(ws + ((long)n * g.C + c4 + j) * 2 + 0, a1[j]);
+            atomicAdd(ws + ((long)n * g.C + c4 + j) * 2 + 1, a2[j]);
+        }
+    }
+}
+
+// ---- backward pass 2: dy through GroupNorm, accumulate dw (and dgamma/dbeta once per (n,c)) -----------------------
+template <int TAPS>
+__global__ __launch_bounds__(NTH) void conv0_bwd_apply_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const bf16_t* __restrict__ dact, const float* __restrict__ ws,
+                                                              float* __restrict__ dw, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, Geo g, int span_max) {
+    extern __shared__ float xs[];
+    float* red = xs + g.C_in * span_max;  // [128][4*TAPS] partials of the odd-time half
+    const int n = blockIdx.y, t0 = blockIdx.x * TC;
+    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
+    stage_audio(xs, audio, g, n, t0, span_max);
+    __syncthreads();
+    const int tmax = min(TC, g.L_out - t0);
+    const float invL = 1.0f / (float)g.L_out;
+    for (int cb = 0; cb < g.C; cb += 512) {
+        const int c4 = cb + cl * 4;
+        const bool live = c4 < g.C;
+        float acc[4][TAPS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = 0.f;
+        if (live) {
+            float w[4][TAPS];
+            load_weights<TAPS>(w, wsrc, c4);
+            float mu[4], rs[4], ga[4], be[4], m1[4], m2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mu[j] = mean[(long)n * g.C + c4 + j]; rs[j] = rstd[(long)n * g.C + c4 + j];
+                ga[j] = gamma[c4 + j]; be[j] = beta[c4 + j];
+                const float A1 = ws[((long)n * g.C + c4 + j) * 2], A2 = ws[((long)n * g.C + c4 + j) * 2 + 1];
+                m1[j] = A1 * invL; m2[j] = A2 * invL;
+                if (blockIdx.x == 0 && half == 0) {
+                    atomicAdd(dbeta + c4 + j, A1);
+                    atomicAdd(dgamma + c4 + j, A2);
+                }
+            }
+            int off[TAPS];
+            tap_offsets<TAPS>(off, g, span_max);
+            for (int tl = half; tl < tmax; tl += 2) {
+                const int t = t0 + tl;
+                float y[4], x[TAPS];
+                conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
+                const bf16x4 d = *reinterpret_cast<const bf16x4*>(dact + ((long)n * g.P + t) * g.C + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (y[j] - mu[j]) * rs[j];
+                    const float dz = bf2f(d[j]) * gelu_grad_f(xh * ga[j] + be[j]);
+                    const float dy = rs[j] * ga[j] * (dz - m1[j] - xh * m2[j]);
+#pragma unroll
+                    for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = fmaf(dy, x[tp], acc[j][tp]);
+                }
+            }
+        }
+        __syncthreads();
+        if (live && half == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) red[(j * TAPS + tp) * 128 + cl] = acc[j][tp];
+        }
+        __syncthreads();
+        if (live && half == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+                    atomicAdd(dw + (long)(c4 + j) * TAPS + tp, acc[j][tp] + red[(j * TAPS + tp) * 128 + cl]);
+        }
+    }
+}
+
+inline Geo geo_of(int N, int C_in, int L, int C, int k, int stride, int L_out, int P) {
+    Geo g; g.N = N; g.C_in = C_in; g.L = L; g.C = C; g.k = k; g.stride = stride; g.L_out = L_out; g.P = P;
+    return g;
+}
+
+template <int TAPS>
+void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStream_t s) {
+    const size_t lds = (size_t)a->C_in * span_max * sizeof(float);
+    dim3 grid1((a->L_out + TC - 1) / TC, a->N), grid2((a->P + TC - 1) / TC, a->N), block(NTH);
+    hipLaunchKernelGGL(conv0_stats_kernel<TAPS>, grid1, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
+                       a->workspace, g, span_max);
+    hipLaunchKernelGGL(conv0_apply_kernel<TAPS>, grid2, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
+                       a->gamma, a->beta, (const float*)a->workspace, (bf16_t*)a->act, a->mean, a->rstd, g, span_max, a->eps);
+}
+
+template <int TAPS>
+void launch_bwd(const wj_conv0_bwd_args* a, const Geo& g, int span_max, hipStream_t s) {
+    const size_t lds1 = (size_t)a->C_in * span_max * sizeof(float);
+    const size_t lds2 = lds1 + (size_t)128 * 4 * TAPS * sizeof(float);
+    dim3 grid((a->L_out + TC - 1) / TC, a->N), block(NTH);
+    hipLaunchKernelGGL(conv0_bwd_stats_kernel<TAPS>, grid, block, lds1, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
+                       a->gamma, a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, a->workspace, g, span_max);
+    hipLaunchKernelGGL(conv0_bwd_apply_kernel<TAPS>, grid, block, lds2, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
+                       a->gamma, a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, (const float*)a->workspace, a->dw,
+                       a->dgamma, a->dbeta, g, span_max);
+}
+
+}  // namespace
+
+extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
+    if (!a || !a->audio || !a->w || !a->gamma || !a->beta || !a->act || !a->mean || !a->rstd || !a->workspace) return WJ_ERR_ARG;
+    if (a->N <= 0 || a->C <= 0 || (a->C & 3) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
+    if ((a->L_out - 1) * a->stride + a->k > a->L) return WJ_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
+    const int span_max = (TC - 1) * a->stride + a->k;
+    if (hipMemsetAsync(a->workspace, 0, sizeof(float) * 2L * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
+    switch (a->C_in * a->k) {
+        case 10: launch_fwd<10>(a, g, span_max, s); break;
+        case 20: launch_fwd<20>(a, g, span_max, s); break;
+        default: return WJ_ERR_UNSUPPORTED;
+    }
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args* a, void* stream) {
+    if (!a || !a->audio || !a->w || !a->gamma || !a->beta || !a->mean || !a->rstd || !a->dact || !a->dw || !a->dgamma ||
+        !a->dbeta || !a->workspace)
+        return WJ_ERR_ARG;
+    if (a->N <= 0 || a->C <= 0 || (a->C & 3) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
+    const int span_max = (TC - 1) * a->stride + a->k;
+    if (hipMemsetAsync(a->workspace, 0, sizeof(float) * 2L * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
+    switch (a->C_in * a->k) {
+        case 10: launch_bwd<10>(a, g, span_max, s); break;
+        case 20: launch_bwd<20>(a, g, span_max, s); break;
+        default: return WJ_ERR_UNSUPPORTED;
+    }
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}

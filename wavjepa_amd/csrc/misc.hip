@@ -1,0 +1,519 @@
+// HBM-bound plumbing kernels of the WavJEPA step for gfx950: token gather/scatter, positions, conv weight layouts,
+// GELU backward, teacher targets (joint instance norm), masked MSE, EMA, AdamW (+ global-norm clip), casts and the
+// crop/normalise batch preparation.  All are vectorised (8-16 B per lane) streaming kernels or small reductions.
+#include <string.h>
+#include "common.h"
+#include "../../include/wavjepa_hip.h"
+
+namespace {
+
+inline int grid_for(long n_items, int per_block, int cap = 8192) {
+    long g = (n_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// ------------------------------------------------------------------------------------------- GELU backward (bf16)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dpost, const bf16_t* __restrict__ pre,
+                                                       bf16_t* __restrict__ dpre, long n8) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dpost + i * 8);
+        const bf16x8 p = *reinterpret_cast<const bf16x8*>(pre + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(d[e]) * gelu_grad_f(bf2f(p[e])));
+        *reinterpret_cast<bf16x8*>(dpre + i * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- conv weight layouts
+__global__ __launch_bounds__(256) void conv_w_kernel(wj_conv_w_args a) {
+    const int Co = a.C_out, Ci = a.C_in, k = a.k;
+    if (a.mode == 0) {  // wp[o][kk*Ci + c] = w[o][c][kk]
+        const long n = (long)Co * Ci * k;
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const int c = (int)(i % Ci);
+            const int kk = (int)((i / Ci) % k);
+            const int o = (int)(i / ((long)Ci * k));
+            ((bf16_t*)a.dst)[i] = f2bf(((const float*)a.src)[((long)o * Ci + c) * k + kk]);
+        }
+    } else if (a.mode == 1) {  // wd[v*Co + o][c] = w[o][c][rho + stride*(U-1-v)]
+        const long n = (long)a.U * Co * Ci;
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const int c = (int)(i % Ci);
+            const int o = (int)((i / Ci) % Co);
+            const int v = (int)(i / ((long)Ci * Co));
+            const int kk = a.rho + a.stride * (a.U - 1 - v);
+            ((bf16_t*)a.dst)[i] = f2bf(((const float*)a.src)[((long)o * Ci + c) * k + kk]);
+        }
+    } else {  // dw[o][c][kk] += dwp[o][kk*Ci + c]
+        const long n = (long)Co * Ci * k;
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const int kk = (int)(i % k);
+            const int c = (int)((i / k) % Ci);
+            const int o = (int)(i / ((long)Ci * k));
+            ((float*)a.dst)[i] += ((const float*)a.src)[(long)o * Ci * k + (long)kk * Ci + c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- + positions
+__global__ __launch_bounds__(256) void add_pos_kernel(wj_add_pos_args a) {
+    const int D4 = a.D / 4;
+    const long n = (long)a.M * D4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / D4), c = (int)(i - (long)m * D4) * 4;
+        const bf16x4 x = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.x + (long)m * a.D + c);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(a.pos + (long)(m % a.T) * a.D + c);
+        f32x4 y;
+        bf16x4 yb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] = bf2f(x[e]) + p[e]; yb[e] = f2bf(y[e]); }
+        if (a.y_f32) *reinterpret_cast<f32x4*>(a.y_f32 + (long)m * a.D + c) = y;
+        if (a.y_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.y_bf16 + (long)m * a.D + c) = yb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- mask gather (bit-exact copy)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ x, const int32_t* __restrict__ idx,
+                                                          char* __restrict__ out, int n_rows, int row_bytes) {
+    const int chunks = row_bytes / 16;
+    for (int j = blockIdx.x; j < n_rows; j += gridDim.x) {
+        const char* s = x + (long)idx[j] * row_bytes;
+        char* d = out + (long)j * row_bytes;
+        for (int c = threadIdx.x; c < chunks; c += 256)
+            *reinterpret_cast<uint4*>(d + c * 16) = *reinterpret_cast<const uint4*>(s + c * 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- predictor input
+__global__ __launch_bounds__(256) void scatter_fill_kernel(wj_scatter_fill_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, M = a.B * a.T;
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        const int b = m / a.T, t = m - b * a.T;
+        const int src = a.inv[m];
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 tok;
+            if (src >= 0) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.ctx_feats + (long)src * D + c);
+                tok = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+            } else {
+                const f32x4 mt = *reinterpret_cast<const f32x4*>(a.mask_token + c);
+                // mask_token.repeat(...).type_as(bf16 features): the token is rounded to bf16 first
+                tok = f32x4{bf2f(f2bf(mt[0])), bf2f(f2bf(mt[1])), bf2f(f2bf(mt[2])), bf2f(f2bf(mt[3]))};
+            }
+            const f32x4 y = tok + *reinterpret_cast<const f32x4*>(a.pos + (long)t * D + c);
+            bf16x4 yb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yb[e] = f2bf(y[e]);
+            for (int g = 0; g < a.G; ++g) {
+                const long orow = ((long)b * a.G + g) * a.T + t;
+                if (a.out_f32) *reinterpret_cast<f32x4*>(a.out_f32 + orow * D + c) = y;
+                if (a.out_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.out_bf16 + orow * D + c) = yb;
+            }
+        }
+    }
+}
+
+constexpr int SFB_ROWS = 64;  // rows per workgroup in the backward
+__global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_bwd_args a) {
+    __shared__ float macc[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, M = a.B * a.T;
+    for (int i = threadIdx.x; i < 1024; i += 256) macc[i] = 0.f;
+    __syncthreads();
+    f32x4 mt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.x * SFB_ROWS;
+    for (int rr = wave; rr < SFB_ROWS; rr += 4) {
+        const int m = r0 + rr;
+        if (m >= M) break;
+        const int b = m / a.T, t = m - b * a.T;
+        const int dst = a.inv[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < D) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < a.G; ++g)
+                    s += *reinterpret_cast<const f32x4*>(a.d_in + (((long)b * a.G + g) * a.T + t) * D + c);
+                if (dst >= 0) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(s[e]);
+                    *reinterpret_cast<bf16x4*>((bf16_t*)a.d_ctx_feats + (long)dst * D + c) = o;
+                } else {
+                    mt[j] += s;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&macc[c + e], mt[j][e]);
+        }
+    }
+    __syncthreads();
+    if (a.d_mask_token)
+        for (int c = threadIdx.x; c < D; c += 256) atomicAdd(a.d_mask_token + c, macc[c]);
+}
+
+// dst_f32[m] = inv[m] >= 0 ? f32(src_bf16[inv[m]]) : 0     (gradient of the mask gather, jepa.py:399)
+__global__ __launch_bounds__(256) void unmask_rows_kernel(wj_unmask_rows_args a) {
+    const int D4 = a.D / 4;
+    const long n = (long)a.M * D4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / D4), c = (int)(i - (long)m * D4) * 4;
+        const int src = a.inv[m];
+        f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (src >= 0) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.src + (long)src * a.D + c);
+            y = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+        }
+        *reinterpret_cast<f32x4*>(a.dst + (long)m * a.D + c) = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- teacher targets
+__global__ __launch_bounds__(1024) void instnorm_kernel(wj_instnorm_args a) {
+    __shared__ float red[16];
+    const long base = (long)blockIdx.x * a.TD;
+    const float* x = a.x + base;
+    const int n4 = a.TD / 4;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        s += v[0] + v[1] + v[2] + v[3];
+    }
+    const float mean = block_sum(s, red) / (float)a.TD;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+    }
+    const float var = block_sum(q, red) / (float)a.TD;
+    const float k = rsqrtf(var + a.eps) * a.scale;
+    float* t = a.targets + base;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * k;
+        if (a.accumulate) o += *reinterpret_cast<const f32x4*>(t + i * 4);
+        *reinterpret_cast<f32x4*>(t + i * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- masked MSE
+__global__ __launch_bounds__(1024) void mse_count_kernel(const uint8_t* __restrict__ tgt, float* __restrict__ ws, long n) {
+    __shared__ float red[16];
+    float c = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) c += tgt[i] ? 1.f : 0.f;
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) ws[1] = c;
+}
+
+__global__ __launch_bounds__(256) void mse_rows_kernel(wj_mse_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D;
+    const long R = (long)a.B * a.G * a.T;
+    const float count = a.workspace[1];
+    const float gk = 2.0f / ((float)D * (count + 1e-8f)) * a.gscale;
+    for (long r = blockIdx.x * 4L + wave; r < R; r += gridDim.x * 4L) {
+        const int t = (int)(r % a.T);
+        const long bg = r / a.T;
+        const int b = (int)(bg / a.G);
+        const bool on = a.tgt[r] != 0;
+        float err = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            bf16x4 dp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[e] = f2bf(0.f);
+            if (on) {
+                const bf16x4 p = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.preds + r * D + c);
+                const f32x4 y = *reinterpret_cast<const f32x4*>(a.targets + ((long)b * a.T + t) * D + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = bf2f(p[e]) - y[e];
+                    err += d * d;
+                    dp[e] = f2bf(d * gk);
+                }
+            }
+            if (a.dpreds) *reinterpret_cast<bf16x4*>((bf16_t*)a.dpreds + r * D + c) = dp;
+        }
+        err = wave_sum(err);
+        if (lane == 0) a.workspace[2 + r] = on ? err / (float)D : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(1024) void mse_final_kernel(float* __restrict__ ws, float* __restrict__ loss, long R) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < R; i += 1024) s += ws[2 + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        loss[0] = s / (ws[1] + 1e-8f);
+        loss[1] = ws[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- EMA / AdamW / norms / casts
+__global__ __launch_bounds__(256) void ema_kernel(wj_ema_args a) {
+    const long n4 = a.n / 4;
+    const float r = a.r, q = 1.0f - a.r;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 s = *reinterpret_cast<const f32x4*>(a.student + i * 4);
+        f32x4 t = *reinterpret_cast<const f32x4*>(a.teacher + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = t[e] * r + q * s[e];
+        *reinterpret_cast<f32x4*>(a.teacher + i * 4) = t;
+        if (a.teacher_bf16) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(t[e]);
+            *reinterpret_cast<bf16x4*>((bf16_t*)a.teacher_bf16 + i * 4) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, float* __restrict__ ws, long n) {
+    __shared__ float red[16];
+    const long n4 = n / 4;
+    float s = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int n) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += ws[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(wj_adamw_args a) {
+    const long n4 = a.n / 4;
+    float coef = a.grad_scale;
+    if (a.max_norm > 0.f && a.sumsq) {
+        const float norm = sqrtf(a.sumsq[0]) * a.grad_scale;
+        coef *= fminf(1.0f, a.max_norm / (norm + 1e-6f));
+    }
+    const float decay = 1.0f - a.lr * a.weight_decay;
+    const float step = a.lr / a.bc1;
+    const float rbc2 = rsqrtf(a.bc2);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i * 4);
+        f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = g[e] * coef;
+            p[e] *= decay;
+            m[e] = a.beta1 * m[e] + (1.0f - a.beta1) * ge;
+            v[e] = a.beta2 * v[e] + (1.0f - a.beta2) * ge * ge;
+            p[e] -= step * m[e] / (sqrtf(v[e]) * rbc2 + a.eps);
+        }
+        *reinterpret_cast<f32x4*>(a.p + i * 4) = p;
+        *reinterpret_cast<f32x4*>(a.m + i * 4) = m;
+        *reinterpret_cast<f32x4*>(a.v + i * 4) = v;
+        if (a.p_bf16) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(p[e]);
+            *reinterpret_cast<bf16x4*>((bf16_t*)a.p_bf16 + i * 4) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long n4 = n / 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 s = *reinterpret_cast<const f32x4*>(src + i * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(s[e]);
+        *reinterpret_cast<bf16x4*>(dst + i * 4) = o;
+    }
+    for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
+}
+
+// ------------------------------------------------------------------------------------------- crop + normalise
+__global__ __launch_bounds__(1024) void crop_kernel(wj_crop_args a) {
+    __shared__ float red[16];
+    const int bs = blockIdx.x, b = bs / a.S;
+    const int start = a.starts[bs];
+    const long n = (long)a.C * a.length;
+    const float* src = a.src + (long)b * a.C * a.L_full;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const int c = (int)(i / a.length), l = (int)(i - (long)c * a.length);
+        s += src[(long)c * a.L_full + start + l];
+    }
+    const float mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const int c = (int)(i / a.length), l = (int)(i - (long)c * a.length);
+        const float d = src[(long)c * a.L_full + start + l] - mean;
+        q += d * d;
+    }
+    const float stdv = sqrtf(block_sum(q, red) / (float)(n - 1));
+    const float inv = 1.0f / (stdv + 1e-5f);
+    const int orow = a.perm_inv ? a.perm_inv[bs] : bs;
+    bf16_t* out = (bf16_t*)a.out + (long)orow * n;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const int c = (int)(i / a.length), l = (int)(i - (long)c * a.length);
+        out[i] = f2bf((src[(long)c * a.L_full + start + l] - mean) * inv);
+    }
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+
+extern "C" int wj_abi_version(void) { return WJ_ABI_VERSION; }
+extern "C" int wj_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int wj_struct_size(const char* name) {
+    if (!name) return -1;
+#define WJ_SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T);
+    WJ_SZ(wj_gemm_args) WJ_SZ(wj_ln_fwd_args) WJ_SZ(wj_ln_bwd_args) WJ_SZ(wj_colsum_args) WJ_SZ(wj_attn_fwd_args)
+    WJ_SZ(wj_attn_bwd_args) WJ_SZ(wj_conv0_fwd_args) WJ_SZ(wj_conv0_bwd_args) WJ_SZ(wj_gelu_bwd_args) WJ_SZ(wj_conv_w_args)
+    WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
+    WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
+    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args)
+#undef WJ_SZ
+    return -1;
+}
+
+extern "C" int wj_gelu_bwd_bf16(const wj_gelu_bwd_args* a, void* stream) {
+    if (!a || !a->dpost || !a->pre || !a->dpre || a->n <= 0 || (a->n & 7)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(a->n / 8, 256)), dim3(256), 0, STREAM, (const bf16_t*)a->dpost,
+                       (const bf16_t*)a->pre, (bf16_t*)a->dpre, (long)(a->n / 8));
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_conv_weight_layout(const wj_conv_w_args* a, void* stream) {
+    if (!a || !a->src || !a->dst || a->C_out <= 0 || a->C_in <= 0 || a->k <= 0 || a->mode < 0 || a->mode > 2) return WJ_ERR_ARG;
+    if (a->mode == 1 && (a->U <= 0 || a->rho < 0 || a->rho + a->stride * (a->U - 1) >= a->k)) return WJ_ERR_ARG;
+    const long n = a->mode == 1 ? (long)a->U * a->C_out * a->C_in : (long)a->C_out * a->C_in * a->k;
+    hipLaunchKernelGGL(conv_w_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_add_pos(const wj_add_pos_args* a, void* stream) {
+    if (!a || !a->x || !a->pos || a->M <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for((long)a->M * a->D / 4, 256)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_mask_gather_rows(const wj_gather_args* a, void* stream) {
+    if (!a || !a->x || !a->idx || !a->out || a->n_rows < 0 || a->D <= 0) return WJ_ERR_ARG;
+    if (a->elem_bytes != 2 && a->elem_bytes != 4) return WJ_ERR_ARG;
+    const int row_bytes = a->D * a->elem_bytes;
+    if (row_bytes & 15) return WJ_ERR_ARG;
+    if (a->n_rows == 0) return WJ_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(a->n_rows, 1, 16384)), dim3(256), 0, STREAM, (const char*)a->x, a->idx,
+                       (char*)a->out, a->n_rows, row_bytes);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_mask_scatter_fill_pos(const wj_scatter_fill_args* a, void* stream) {
+    if (!a || !a->ctx_feats || !a->inv || !a->mask_token || !a->pos || a->B <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3) ||
+        a->G <= 0)
+        return WJ_ERR_ARG;
+    hipLaunchKernelGGL(scatter_fill_kernel, dim3(grid_for((long)a->B * a->T, 4)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args* a, void* stream) {
+    if (!a || !a->d_in || !a->inv || !a->d_ctx_feats || a->B <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3) || a->D > 1024 ||
+        a->G <= 0)
+        return WJ_ERR_ARG;
+    const int grid = (a->B * a->T + SFB_ROWS - 1) / SFB_ROWS;
+    hipLaunchKernelGGL(scatter_fill_bwd_kernel, dim3(grid), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_unmask_rows_f32(const wj_unmask_rows_args* a, void* stream) {
+    if (!a || !a->src || !a->inv || !a->dst || a->M <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(unmask_rows_kernel, dim3(grid_for((long)a->M * a->D / 4, 256)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_instnorm_accumulate(const wj_instnorm_args* a, void* stream) {
+    if (!a || !a->x || !a->targets || a->B <= 0 || a->TD <= 0 || (a->TD & 3)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(instnorm_kernel, dim3(a->B), dim3(1024), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_masked_mse(const wj_mse_args* a, void* stream) {
+    if (!a || !a->preds || !a->targets || !a->tgt || !a->loss || !a->workspace) return WJ_ERR_ARG;
+    if (a->B <= 0 || a->G <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
+    const long R = (long)a->B * a->G * a->T;
+    hipLaunchKernelGGL(mse_count_kernel, dim3(1), dim3(1024), 0, STREAM, a->tgt, a->workspace, R);
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(grid_for(R, 4)), dim3(256), 0, STREAM, *a);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(1024), 0, STREAM, a->workspace, a->loss, R);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_ema_update(const wj_ema_args* a, void* stream) {
+    if (!a || !a->student || !a->teacher || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(a->n / 4, 256)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_grad_sumsq(const wj_sumsq_args* a, void* stream) {
+    if (!a || !a->g || !a->out || !a->workspace || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
+    const int grid = grid_for(a->n / 4, 256, 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, STREAM, a->g, a->workspace, (long)a->n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, STREAM, (const float*)a->workspace, a->out, grid);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_adamw_step(const wj_adamw_args* a, void* stream) {
+    if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n / 4, 256)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_cast_f32_to_bf16(const wj_cast_args* a, void* stream) {
+    if (!a || !a->src || !a->dst || a->n <= 0) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(a->n / 4 + 1, 256)), dim3(256), 0, STREAM, a->src, (bf16_t*)a->dst, (long)a->n);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_crop_normalize_bf16(const wj_crop_args* a, void* stream) {
+    if (!a || !a->src || !a->starts || !a->out || a->B <= 0 || a->S <= 0 || a->C <= 0 || a->length <= 1 || a->L_full < a->length)
+        return WJ_ERR_ARG;
+    hipLaunchKernelGGL(crop_kernel, dim3(a->B * a->S), dim3(1024), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}

@@ -1,0 +1,237 @@
+// LayerNorm forward/backward (fp32 statistics, fused post-norm residual add) and bf16 column sums for gfx950.
+// HBM-bound kernels: one 64-lane wave owns a row, 16-B (fp32) / 8-B (bf16) vector accesses, wave-shuffle
+// reductions; column (parameter-gradient) partials are combined in LDS before one global atomic per column per
+// workgroup.
+#include "common.h"
+#include "../../include/wavjepa_hip.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 chunks per lane: D <= 1024
+
+__device__ __forceinline__ long remap_row(int m, int seg, int valid) {
+    return seg > 0 ? (long)(m / valid) * seg + (m % valid) : (long)m;
+}
+
+__device__ __forceinline__ f32x4 load4(const void* base, long row, int D, int col, bool is_bf16) {
+    if (is_bf16) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)base + row * D + col);
+        return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+    }
+    return *reinterpret_cast<const f32x4*>((const float*)base + row * D + col);
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D;
+    const float invD = 1.0f / (float)D;
+    for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
+        const long xr = remap_row(m, a.in_seg, a.in_valid);
+        f32x4 s[MAXV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int col = lane * 4 + 256 * j;
+            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col < D) {
+                s[j] = load4(a.x, xr, D, col, a.x_is_bf16);
+                if (a.r) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.r + (long)m * D + col);
+                    s[j] += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+                }
+                sum += s[j][0] + s[j][1] + s[j][2] + s[j][3];
+            }
+        }
+        const float mean = wave_sum(sum) * invD;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int col = lane * 4 + 256 * j;
+            if (col < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = s[j][e] - mean;
+                    sq += d * d;
+                }
+            }
+        }
+        const float var = wave_sum(sq) * invD;
+        const float rstd = rsqrtf(var + a.eps);
+        if (lane == 0) {
+            if (a.mean) a.mean[m] = mean;
+            if (a.rstd) a.rstd[m] = rstd;
+        }
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int col = lane * 4 + 256 * j;
+            if (col < D) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + col);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.beta + col);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (s[j][e] - mean) * rstd * g[e] + b[e];
+                if (a.y_f32) *reinterpret_cast<f32x4*>(a.y_f32 + (long)m * D + col) = y;
+                if (a.y_bf16) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(y[e]);
+                    *reinterpret_cast<bf16x4*>((bf16_t*)a.y_bf16 + (long)m * D + col) = o;
+                }
+            }
+        }
+    }
+}
+
+constexpr int BWD_THREADS = 512;
+
+__global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
+    __shared__ float cacc[3][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = BWD_THREADS / 64;
+    const int D = a.D;
+    const float invD = 1.0f / (float)D;
+    for (int i = threadIdx.x; i < 3 * 1024; i += BWD_THREADS) (&cacc[0][0])[i] = 0.f;
+    __syncthreads();
+
+    f32x4 dg[MAXV], db[MAXV], dbi[MAXV];
+    f32x4 gam[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        dg[j] = db[j] = dbi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int col = lane * 4 + 256 * j;
+        gam[j] = col < D ? *reinterpret_cast<const f32x4*>(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int m = blockIdx.x * nw + wave; m < a.M; m += gridDim.x * nw) {
+        const long xr = remap_row(m, a.in_seg, a.in_valid);
+        const float mean = a.mean[m], rstd = a.rstd[m];
+        f32x4 xh[MAXV], dy[MAXV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int col = lane * 4 + 256 * j;
+            xh[j] = dy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col < D) {
+                f32x4 s = load4(a.x, xr, D, col, a.x_is_bf16);
+                if (a.r) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.r + (long)m * D + col);
+                    s += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+                }
+                dy[j] = *reinterpret_cast<const f32x4*>(a.dy + (long)m * D + col);
+                if (a.dy2) dy[j] += *reinterpret_cast<const f32x4*>(a.dy2 + (long)m * D + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[j][e] = (s[e] - mean) * rstd;
+                    const float g = dy[j][e] * gam[j][e];
+                    c1 += g;
+                    c2 += g * xh[j][e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) * invD;
+        c2 = wave_sum(c2) * invD;
+        const long orow = remap_row(m, a.out_seg, a.out_valid);
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int col = lane * 4 + 256 * j;
+            if (col < D) {
+                f32x4 ds;
+                bf16x4 dsb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ds[e] = rstd * (dy[j][e] * gam[j][e] - c1 - xh[j][e] * c2);
+                    dsb[e] = f2bf(ds[e]);
+                    dg[j][e] += dy[j][e] * xh[j][e];
+                    db[j][e] += dy[j][e];
+                    dbi[j][e] += bf2f(dsb[e]);
+                }
+                if (a.ds_f32) *reinterpret_cast<f32x4*>(a.ds_f32 + (long)m * D + col) = ds;
+                if (a.ds_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.ds_bf16 + orow * D + col) = dsb;
+            }
+        }
+    }
+    // combine the column partials of the 8 waves in LDS, then one global atomic per column per workgroup
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int col = lane * 4 + 256 * j;
+        if (col < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&cacc[0][col + e], dg[j][e]);
+                atomicAdd(&cacc[1][col + e], db[j][e]);
+                if (a.dbias) atomicAdd(&cacc[2][col + e], dbi[j][e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += BWD_THREADS) {
+        if (a.dgamma) atomicAdd(a.dgamma + c, cacc[0][c]);
+        if (a.dbeta) atomicAdd(a.dbeta + c, cacc[1][c]);
+        if (a.dbias) atomicAdd(a.dbias + c, cacc[2][c]);
+    }
+}
+
+// column sums: workgroup = 64 columns x a row range; thread (cc = t&7 -> 8 columns, rl = t>>3 -> row lane of 32)
+__global__ __launch_bounds__(256) void colsum_kernel(wj_colsum_args a, int rows_per_wg) {
+    __shared__ float red[32][65];
+    const int t = threadIdx.x, cc = t & 7, rl = t >> 3;
+    const int col = blockIdx.x * 64 + cc * 8;
+    const int r0 = blockIdx.y * rows_per_wg;
+    const int r1 = min(a.M, r0 + rows_per_wg);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < a.N) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>((const bf16_t*)a.x + (long)r * a.ldx + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cc * 8 + e] = acc[e];
+    __syncthreads();
+    if (t < 64) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) s += red[r][t];
+        const int c = blockIdx.x * 64 + t;
+        if (c < a.N) atomicAdd(a.out + c, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
+    if (!a || !a->x || !a->gamma || !a->beta) return WJ_ERR_ARG;
+    if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
+    if (a->in_seg > 0 && a->in_valid <= 0) return WJ_ERR_ARG;
+    int grid = (a->M + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
+    if (!a || !a->dy || !a->x || !a->gamma || !a->mean || !a->rstd) return WJ_ERR_ARG;
+    if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
+    if ((a->in_seg > 0 && a->in_valid <= 0) || (a->out_seg > 0 && a->out_valid <= 0)) return WJ_ERR_ARG;
+    const int nw = BWD_THREADS / 64;
+    int grid = (a->M + nw - 1) / nw;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_colsum_bf16(const wj_colsum_args* a, void* stream) {
+    if (!a || !a->x || !a->out || a->M <= 0 || a->N <= 0 || (a->N & 7) || (a->ldx & 7)) return WJ_ERR_ARG;
+    const int gx = (a->N + 63) / 64;
+    int gy = 2048 / gx;
+    if (gy < 1) gy = 1;
+    int rows = (a->M + gy - 1) / gy;
+    rows = (rows + 31) / 32 * 32;
+    gy = (a->M + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, *a, rows);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}

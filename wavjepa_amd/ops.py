@@ -1,0 +1,193 @@
+"""Thin Python wrappers over the C ABI of libwavjepa_hip.so (one function per entry point).
+
+Arguments are torch tensors (device memory owned by PyTorch's caching allocator) or raw integer device pointers;
+every call is enqueued on PyTorch's *current* HIP stream and returns immediately.  Nothing here computes on the
+host and nothing falls back to PyTorch ops: a missing library or a non-zero return code raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import torch
+
+from . import _abi
+from ._abi import ENUMS, STRUCTS
+
+Ptr = Union[torch.Tensor, int, None]
+
+EPI_BF16 = ENUMS["WJ_EPI_BF16"]
+EPI_BIAS_GELU2 = ENUMS["WJ_EPI_BIAS_GELU2"]
+EPI_MUL_GELU_GRAD = ENUMS["WJ_EPI_MUL_GELU_GRAD"]
+EPI_ADD_F32 = ENUMS["WJ_EPI_ADD_F32"]
+EPI_ATOMIC_F32 = ENUMS["WJ_EPI_ATOMIC_F32"]
+EPI_CONV_GELU = ENUMS["WJ_EPI_CONV_GELU"]
+
+
+def _p(x: Ptr) -> int:
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _run(fn: str, struct_name: str, stream: Optional[int], **fields) -> None:
+    a = STRUCTS[struct_name]()
+    for k, v in fields.items():
+        setattr(a, k, v)
+    _abi.call(fn, a, _stream() if stream is None else stream)
+
+
+def require_gpu() -> None:
+    _abi.load()
+    if not torch.cuda.is_available():
+        raise _abi.WavJepaHipError("wavjepa_amd needs a HIP device (MI355X); there is no CPU fallback")
+
+
+# ---------------------------------------------------------------------------------------------------------- GEMM
+def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, a_trans: int = 0,
+         b_trans: int = 0, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, aux: Ptr = None, split_k: int = 1,
+         seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, stream: Optional[int] = None) -> None:
+    _run("wj_gemm_bf16", "wj_gemm_args", stream, A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), aux=_p(aux),
+         lda=lda, ldb=ldb, ldc=ldc, M=M, N=N, K=K, a_trans=a_trans, b_trans=b_trans, epilogue=epilogue, split_k=split_k,
+         seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
+
+
+def pick_split_k(M: int, N: int, K: int, target_wgs: int = 512) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, target_wgs // max(1, tiles))
+    return max(1, min(s, (K + 511) // 512))
+
+
+# ---------------------------------------------------------------------------------------------------------- norms
+def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, r: Ptr = None, y_f32: Ptr = None,
+                  y_bf16: Ptr = None, mean: Ptr = None, rstd: Ptr = None, x_is_bf16: bool = False, in_seg: int = 0,
+                  in_valid: int = 0, stream: Optional[int] = None) -> None:
+    _run("wj_layernorm_fwd", "wj_ln_fwd_args", stream, x=_p(x), r=_p(r), gamma=_p(gamma), beta=_p(beta), y_f32=_p(y_f32),
+         y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg,
+         in_valid=in_valid, eps=eps)
+
+
+def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
+                  ds_f32: Ptr = None, ds_bf16: Ptr = None, dgamma: Ptr = None, dbeta: Ptr = None, dbias: Ptr = None,
+                  x_is_bf16: bool = False, in_seg: int = 0, in_valid: int = 0, out_seg: int = 0, out_valid: int = 0,
+                  stream: Optional[int] = None) -> None:
+    _run("wj_layernorm_bwd", "wj_ln_bwd_args", stream, dy=_p(dy), dy2=_p(dy2), x=_p(x), r=_p(r), gamma=_p(gamma),
+         mean=_p(mean), rstd=_p(rstd), ds_f32=_p(ds_f32), ds_bf16=_p(ds_bf16), dgamma=_p(dgamma), dbeta=_p(dbeta),
+         dbias=_p(dbias), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, out_seg=out_seg,
+         out_valid=out_valid)
+
+
+def colsum_bf16(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[int] = None) -> None:
+    _run("wj_colsum_bf16", "wj_colsum_args", stream, x=_p(x), out=_p(out), ldx=ldx, M=M, N=N)
+
+
+# ---------------------------------------------------------------------------------------------------------- attention
+def attn_fwd(qkv: Ptr, out: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None, lse: Ptr = None,
+             mask_group: int = 1, stream: Optional[int] = None) -> None:
+    _run("wj_attn_fwd", "wj_attn_fwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), out=_p(out), lse=_p(lse), B=B, T=T,
+         H=H, hd=hd, mask_group=mask_group)
+
+
+def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None,
+             mask_group: int = 1, stream: Optional[int] = None) -> None:
+    _run("wj_attn_bwd", "wj_attn_bwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), out=_p(out), dout=_p(dout),
+         lse=_p(lse), dqkv=_p(dqkv), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
+
+
+# ---------------------------------------------------------------------------------------------------------- conv front-end
+def conv0_fwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, act: Ptr, mean: Ptr, rstd: Ptr, workspace: Ptr, *, N: int,
+              C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int, eps: float = 1e-5,
+              stream: Optional[int] = None) -> None:
+    _run("wj_conv0_gn_gelu_fwd", "wj_conv0_fwd_args", stream, audio=_p(audio), w=_p(w), gamma=_p(gamma), beta=_p(beta),
+         act=_p(act), mean=_p(mean), rstd=_p(rstd), workspace=_p(workspace), N=N, C_in=C_in, L=L, C=C, k=k, stride=stride,
+         L_out=L_out, P=P, eps=eps)
+
+
+def conv0_bwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, mean: Ptr, rstd: Ptr, dact: Ptr, dw: Ptr, dgamma: Ptr, dbeta: Ptr,
+              workspace: Ptr, *, N: int, C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int,
+              stream: Optional[int] = None) -> None:
+    _run("wj_conv0_gn_gelu_bwd", "wj_conv0_bwd_args", stream, audio=_p(audio), w=_p(w), gamma=_p(gamma), beta=_p(beta),
+         mean=_p(mean), rstd=_p(rstd), dact=_p(dact), dw=_p(dw), dgamma=_p(dgamma), dbeta=_p(dbeta), workspace=_p(workspace),
+         N=N, C_in=C_in, L=L, C=C, k=k, stride=stride, L_out=L_out, P=P)
+
+
+def gelu_bwd_bf16(dpost: Ptr, pre: Ptr, dpre: Ptr, n: int, stream: Optional[int] = None) -> None:
+    _run("wj_gelu_bwd_bf16", "wj_gelu_bwd_args", stream, dpost=_p(dpost), pre=_p(pre), dpre=_p(dpre), n=n)
+
+
+def conv_weight_layout(src: Ptr, dst: Ptr, *, C_out: int, C_in: int, k: int, mode: int, stride: int = 1, rho: int = 0,
+                       U: int = 1, stream: Optional[int] = None) -> None:
+    _run("wj_conv_weight_layout", "wj_conv_w_args", stream, src=_p(src), dst=_p(dst), C_out=C_out, C_in=C_in, k=k,
+         stride=stride, rho=rho, U=U, mode=mode)
+
+
+# ---------------------------------------------------------------------------------------------------------- tokens
+def add_pos(x: Ptr, pos: Ptr, *, M: int, T: int, D: int, y_f32: Ptr = None, y_bf16: Ptr = None,
+            stream: Optional[int] = None) -> None:
+    _run("wj_add_pos", "wj_add_pos_args", stream, x=_p(x), pos=_p(pos), y_f32=_p(y_f32), y_bf16=_p(y_bf16), M=M, T=T, D=D)
+
+
+def mask_gather_rows(x: Ptr, idx: Ptr, out: Ptr, *, n_rows: int, D: int, elem_bytes: int, stream: Optional[int] = None) -> None:
+    _run("wj_mask_gather_rows", "wj_gather_args", stream, x=_p(x), idx=_p(idx), out=_p(out), n_rows=n_rows, D=D,
+         elem_bytes=elem_bytes)
+
+
+def mask_scatter_fill_pos(ctx_feats: Ptr, inv: Ptr, mask_token: Ptr, pos: Ptr, *, B: int, T: int, D: int, G: int,
+                          out_f32: Ptr = None, out_bf16: Ptr = None, stream: Optional[int] = None) -> None:
+    _run("wj_mask_scatter_fill_pos", "wj_scatter_fill_args", stream, ctx_feats=_p(ctx_feats), inv=_p(inv),
+         mask_token=_p(mask_token), pos=_p(pos), out_f32=_p(out_f32), out_bf16=_p(out_bf16), B=B, T=T, D=D, G=G)
+
+
+def mask_scatter_fill_pos_bwd(d_in: Ptr, inv: Ptr, d_ctx_feats: Ptr, d_mask_token: Ptr, *, B: int, T: int, D: int, G: int,
+                              stream: Optional[int] = None) -> None:
+    _run("wj_mask_scatter_fill_pos_bwd", "wj_scatter_fill_bwd_args", stream, d_in=_p(d_in), inv=_p(inv),
+         d_ctx_feats=_p(d_ctx_feats), d_mask_token=_p(d_mask_token), B=B, T=T, D=D, G=G)
+
+
+def unmask_rows_f32(src: Ptr, inv: Ptr, dst: Ptr, *, M: int, D: int, stream: Optional[int] = None) -> None:
+    _run("wj_unmask_rows_f32", "wj_unmask_rows_args", stream, src=_p(src), inv=_p(inv), dst=_p(dst), M=M, D=D)
+
+
+# ---------------------------------------------------------------------------------------------------------- targets / loss
+def instnorm_accumulate(x: Ptr, targets: Ptr, *, B: int, TD: int, accumulate: bool, scale: float, eps: float = 1e-5,
+                        stream: Optional[int] = None) -> None:
+    _run("wj_instnorm_accumulate", "wj_instnorm_args", stream, x=_p(x), targets=_p(targets), B=B, TD=TD,
+         accumulate=int(accumulate), scale=scale, eps=eps)
+
+
+def masked_mse(preds: Ptr, targets: Ptr, tgt: Ptr, loss: Ptr, workspace: Ptr, *, B: int, G: int, T: int, D: int,
+               dpreds: Ptr = None, gscale: float = 1.0, stream: Optional[int] = None) -> None:
+    _run("wj_masked_mse", "wj_mse_args", stream, preds=_p(preds), targets=_p(targets), tgt=_p(tgt), loss=_p(loss),
+         dpreds=_p(dpreds), workspace=_p(workspace), B=B, G=G, T=T, D=D, gscale=gscale)
+
+
+# ---------------------------------------------------------------------------------------------------------- optimiser side
+def ema_update(student: Ptr, teacher: Ptr, n: int, r: float, teacher_bf16: Ptr = None, stream: Optional[int] = None) -> None:
+    _run("wj_ema_update", "wj_ema_args", stream, student=_p(student), teacher=_p(teacher), teacher_bf16=_p(teacher_bf16), n=n, r=r)
+
+
+def grad_sumsq(g: Ptr, out: Ptr, workspace: Ptr, n: int, stream: Optional[int] = None) -> None:
+    _run("wj_grad_sumsq", "wj_sumsq_args", stream, g=_p(g), out=_p(out), workspace=_p(workspace), n=n)
+
+
+def adamw_step(p: Ptr, g: Ptr, m: Ptr, v: Ptr, n: int, *, lr: float, beta1: float, beta2: float, eps: float,
+               weight_decay: float, step: int, max_norm: float = 0.0, sumsq: Ptr = None, p_bf16: Ptr = None,
+               grad_scale: float = 1.0, stream: Optional[int] = None) -> None:
+    _run("wj_adamw_step", "wj_adamw_args", stream, p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p_bf16), sumsq=_p(sumsq),
+         n=n, lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, bc1=1.0 - beta1 ** step,
+         bc2=1.0 - beta2 ** step, max_norm=max_norm, grad_scale=grad_scale)
+
+
+def cast_f32_to_bf16(src: Ptr, dst: Ptr, n: int, stream: Optional[int] = None) -> None:
+    _run("wj_cast_f32_to_bf16", "wj_cast_args", stream, src=_p(src), dst=_p(dst), n=n)
+
+
+def crop_normalize_bf16(src: Ptr, starts: Ptr, out: Ptr, *, B: int, S: int, C: int, L_full: int, length: int,
+                        perm_inv: Ptr = None, stream: Optional[int] = None) -> None:
+    _run("wj_crop_normalize_bf16", "wj_crop_args", stream, src=_p(src), starts=_p(starts), perm_inv=_p(perm_inv), out=_p(out),
+         B=B, S=S, C=C, L_full=L_full, length=length)
