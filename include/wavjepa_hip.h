@@ -34,7 +34,8 @@ int wj_struct_size(const char* name);
  * channels-last activation (extractors/audio_feature_extractor.py:66-70).
  *   C[M,N] = opA(A) . opB(B);  a_trans=0: A is [M][K] (K contiguous);  a_trans=1: A is stored [K][M] (M contiguous)
  *                              b_trans=0: B is [N][K] (K contiguous);  b_trans=1: B is stored [K][N] (N contiguous)
- * Requirements: N%8==0, K%8==0, lda%8==0, ldb%8==0, ldc%4==0; a_trans also needs M%8==0.
+ * Requirements: N%8==0, lda%8==0, ldb%8==0, ldc%4==0; a_trans also needs M%8==0; K%8==0 unless both operands are
+ * col form (wgrad: K = token rows, arbitrary).
  * -----------------------------------------------------------------------------------------------------------*/
 enum {
     WJ_EPI_BF16 = 0,          /* C(bf16)  = acc (+ bias[n])                                                  */
@@ -291,6 +292,7 @@ typedef struct {
     float* loss;
     void* dpreds;
     float* workspace;
+    const float* gscale_ptr; /* optional DEVICE scalar multiplied into gscale (the upstream d(loss), no host sync) */
     int32_t B, G, T, D;
     float gscale;
 } wj_mse_args;

@@ -1,0 +1,175 @@
+"""End-to-end parity of the HIP path (wavjepa_amd.JEPA through the C ABI) against the oracle on the same seeded
+inputs (GPU only).  Tolerances: loss within 1e-3 relative of the oracle's bf16 mode (the north-star criterion);
+bf16 activations within 1e-2 relative L2; mask gather bit-exact; parameter gradients within 3e-2 relative L2 per
+tensor group (two independent bf16 pipelines)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import jepa_oracle as J
+
+pytestmark = pytest.mark.gpu
+
+SMALL_SPEC = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)]
+SMALL = dict(conv_spec=SMALL_SPEC, d_enc=128, h_enc=2, l_enc=2, d_dec=64, h_dec=2, l_dec=2, top_k=2)
+BASE = dict(conv_spec=list(J.WAVJEPA_CONV_SPEC), d_enc=768, h_enc=12, l_enc=12, d_dec=384, h_dec=12, l_dec=12, top_k=8)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(cfg, seed=7, teacher_scale=0.97, **kw):
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.jepa import JEPA
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    ext = ConvFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=1)
+    m = JEPA(feature_extractor=ext,
+             transformer_encoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_enc"]),
+             transformer_encoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_enc"], nhead=cfg["h_enc"]),
+             transformer_decoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_dec"]),
+             transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_dec"], nhead=cfg["h_dec"]),
+             lr=4e-4, adam_betas=(0.9, 0.98), adam_weight_decay=0.04, average_top_k_layers=cfg["top_k"],
+             process_audio_seconds=2.01, nr_samples_per_audio=2, **kw)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=seed)
+    for k in list(sd):
+        if k.startswith("teacher_encoder.") and k.endswith("weight") and sd[k].ndim == 2:
+            sd[k] = (sd[k] * np.float32(teacher_scale)).astype(np.float32)
+    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    sd["pos_encoding_encoder"] = J.sincos_positions(cfg["d_enc"], 200)
+    sd["pos_encoding_decoder"] = J.sincos_positions(cfg["d_dec"], 200)
+    m.load_state_dict(sd)
+    P = {k: v.clone().to(dev()) for k, v in sd.items()}
+    return m.to(dev()), P
+
+
+def masks(golden_dir, n):
+    fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    return tuple(torch.from_numpy(fx[k][:n]) for k in ("as_ctx", "as_tgt", "as_vis"))
+
+
+def oracle_kw(cfg):
+    return dict(spec=cfg["conv_spec"], enc_heads=cfg["h_enc"], dec_heads=cfg["h_dec"], top_k=cfg["top_k"])
+
+
+def group_of(name):
+    for g in ("extract_audio", "feature_norms", "post_extraction_mapper", "encoder_to_decoder_mapper",
+              "decoder_to_encoder_mapper", "encoder", "decoder", "mask_token"):
+        if name.startswith(g):
+            return g
+    return "other"
+
+
+@pytest.mark.parametrize("cfg_name,n", [("small", 4), ("base", 2)])
+def test_forward_backward_parity(golden_dir, cfg_name, n):
+    cfg = SMALL if cfg_name == "small" else BASE
+    m, P = build(cfg)
+    ctx, tgt, vis = masks(golden_dir, n)
+    audio = torch.from_numpy(synth.synth_audio(n, 1, 32159, seed=3)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt, vis)
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(cfg))
+    ref32 = J.jepa_forward({k: v.detach() for k, v in P.items()}, audio.float(), ctx.to(dev()), tgt.to(dev()), vis.to(dev()),
+                           mode="fp32", **oracle_kw(cfg))
+    report = {k: rel(out[k].float(), ref[k].float()) for k in ("local_features", "contextual_features", "preds", "targets")}
+    lo, lr_, l32 = float(out["loss"]), float(ref["loss"]), float(ref32["loss"])
+    print(cfg_name, "rel errors vs oracle bf16:", report, "loss hip/oracle-bf16/oracle-fp32:", lo, lr_, l32)
+    assert out["local_features"].dtype == torch.float32 and out["preds"].dtype == torch.bfloat16
+    assert out["contextual_features"].shape == ref["contextual_features"].shape
+    assert report["local_features"] < 1e-2 and report["targets"] < 1e-2
+    assert report["contextual_features"] < 2e-2 and report["preds"] < 2e-2
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)          # north-star: loss within 1e-3 rel of the bf16 reference flow
+    assert abs(lo - l32) < 2e-2 * abs(l32)
+    # backward
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    num, den = {}, {}
+    for k in names:
+        g = group_of(k)
+        a, b = got[k].grad.double(), P[k].grad.double()
+        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
+    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    print(cfg_name, "grad rel errors per group:", errs)
+    for g, e in errs.items():
+        assert e < 3e-2, (g, e)
+
+
+def test_mask_gather_bit_exact_and_shapes(golden_dir):
+    m, P = build(SMALL)
+    ctx, tgt, vis = masks(golden_dir, 3)
+    audio = torch.from_numpy(synth.synth_audio(3, 1, 32159, seed=5)).to(torch.bfloat16).to(dev())
+    with torch.no_grad():
+        m(audio, ctx, tgt, vis)
+    eng = m._engine
+    n_ctx = int((~ctx).sum())
+    assert eng.plan.n_ctx == n_ctx
+    want = eng.enc_out_b.view(3, 200, -1)[(~ctx).to(dev())]
+    assert torch.equal(eng.ctx_in[:n_ctx], want)                     # pure copy in (b, t) row-major order
+
+
+def test_training_trajectory_vs_oracle(golden_dir):
+    """10 optimisation steps (forward, EMA, backward, clip 5, AdamW, cosine/warm-up) against the oracle's train_step."""
+    m, P = build(SMALL, warmup_steps=3)
+    P = {k: v.detach().clone() for k, v in P.items()}
+    m.trainer.max_steps = 20
+    m.hparams["ema_decay"], m.hparams["ema_end_decay"], m.ema_end_step = 0.9, 0.99, 10
+    oc = m.configure_optimizers()
+    opt, sch = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    opt.max_grad_norm = 5.0
+    ctx, tgt, vis = masks(golden_dir, 6)
+    state = {}
+    worst = 0.0
+    for i in range(10):
+        sl = slice(2 * (i % 3), 2 * (i % 3) + 2)
+        audio = torch.from_numpy(synth.synth_audio(2, 1, 32159, seed=100 + i % 3)).to(torch.bfloat16).to(dev())
+        batch = (audio, ctx[sl], tgt[sl], vis[sl])
+        m.global_step = i
+        out = m.training_step(batch, i)
+        out["loss"].backward()
+        opt.step()
+        sch.step()
+        r = J.train_step(P, state, i, (audio, ctx[sl].to(dev()), tgt[sl].to(dev()), vis[sl].to(dev())), mode="bf16", warmup=3,
+                         total_steps=20, ema=(0.9, 0.99, 10), **oracle_kw(SMALL))
+        lo = float(out["loss"])
+        worst = max(worst, abs(lo - r["loss"]) / abs(r["loss"]))
+        gn = float(opt.grad_norm())
+        assert abs(gn - r["grad_norm"]) < 3e-2 * r["grad_norm"], (i, gn, r["grad_norm"])
+    print("worst relative loss deviation over 10 steps:", worst)
+    assert worst < 2e-3
+    sd = m.state_dict()
+    for k in ("encoder.layers.1.linear1.weight", "teacher_encoder.layers.1.linear1.weight", "extract_audio.cnn.2.0.weight"):
+        assert rel(sd[k], P[k]) < 2e-3, k
+
+
+def test_inference_representation(golden_dir):
+    m, P = build(SMALL)
+    audio = torch.from_numpy(synth.synth_audio(2, 1, 32159, seed=9)).to(dev())
+    pad = torch.zeros(2, 200, dtype=torch.bool)
+    pad[:, 150:] = True
+    rep = m.get_audio_representation(audio, pad.to(dev()))
+    ref = J.audio_representation(P, audio.to(torch.bfloat16), pad.to(dev()), spec=SMALL_SPEC, enc_heads=2, mode="bf16")
+    assert rep.shape == (2, 200, 128) and rel(rep[:, :150], ref[:, :150]) < 1e-2
+
+
+def test_state_dict_roundtrip_and_reference_checkpoint_layout():
+    m, P = build(SMALL)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    shapes = synth.jepa_shapes(conv_spec=SMALL_SPEC, in_channels=1, d_enc=128, enc_layers=2, d_dec=64, dec_layers=2, n_tokens=200)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == shapes
+    m2, _ = build(SMALL, seed=11)
+    m2.load_state_dict(sd)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k

@@ -279,7 +279,8 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
 extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return WJ_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return WJ_ERR_ARG;
-    if ((a->N & 7) || (a->K & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3)) return WJ_ERR_ARG;
+    if ((a->N & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3)) return WJ_ERR_ARG;
+    if ((!a->a_trans || !a->b_trans) && (a->K & 7)) return WJ_ERR_ARG;  // row-form operands are read in 8-element K chunks
     if (a->a_trans && (a->M & 7)) return WJ_ERR_ARG;
     if ((a->epilogue == WJ_EPI_BIAS_GELU2 || a->epilogue == WJ_EPI_CONV_GELU) && !a->C2) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD && !a->aux) return WJ_ERR_ARG;

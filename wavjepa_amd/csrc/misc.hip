@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(wj_mse_args a) {
     const int D = a.D;
     const long R = (long)a.B * a.G * a.T;
     const float count = a.workspace[1];
-    const float gk = 2.0f / ((float)D * (count + 1e-8f)) * a.gscale;
+    const float gk = 2.0f / ((float)D * (count + 1e-8f)) * a.gscale * (a.gscale_ptr ? a.gscale_ptr[0] : 1.0f);
     for (long r = blockIdx.x * 4L + wave; r < R; r += gridDim.x * 4L) {
         const int t = (int)(r % a.T);
         const long bg = r / a.T;

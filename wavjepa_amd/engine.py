@@ -1,0 +1,498 @@
+"""Forward/backward orchestration of the WavJEPA pre-training step on one MI355X.
+
+This is the host side of the hot path: a fixed sequence of C-ABI kernel launches over a pre-allocated activation
+arena (no autograd graph, no allocator traffic in the step, no host synchronisation), mirroring
+reference wavjepa/jepa.py:365-419 (forward), :230-270 (teacher targets), :335-362 (loss) and the implicit autograd
+backward of those ops.  Activations are token-major bf16/fp32 buffers sized once per batch size; the residual
+stream is fp32 and every GEMM operand is bf16, exactly the dtype flow bf16 autocast produces on the reference.
+
+Conv front-end layout: channels-last [clip][row][C] with per-clip row counts P_l chosen so that
+P_{l-1} = stride_l * P_l; a strided conv is then ONE GEMM with lda = stride*C and K = k*C over all clips
+(rows >= L_l of a clip are padding, kept at zero).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .params import FlatParams
+
+
+@dataclass
+class EngineConfig:
+    conv_spec: Sequence[Tuple[int, int, int]]
+    in_channels: int
+    n_samples: int          # waveform samples per clip (32159)
+    d_enc: int
+    h_enc: int
+    l_enc: int
+    d_dec: int
+    h_dec: int
+    l_dec: int
+    top_k: int
+    groups: int = 4
+    ln_eps: float = 1e-6    # transformer layers (reference types/wavjepa_configs.py:37)
+    norm_eps: float = 1e-5  # feature_norms / final norms (nn.LayerNorm default)
+
+
+@dataclass
+class MaskPlan:
+    """Device-side masks + the index lists of the boolean-mask gather (reference jepa.py:399,425-428)."""
+    ctx_u8: torch.Tensor    # [N, T]     1 = NOT context (key masked for the student)
+    tgt_u8: torch.Tensor    # [N, G, T]  1 = target position
+    vis_u8: torch.Tensor    # [N*G, T]   1 = key masked for the predictor
+    keep: torch.Tensor      # int32 [n_ctx] flat (b*T+t) of context rows, ascending
+    inv: torch.Tensor       # int32 [N*T]  position in `keep` or -1
+    n_ctx: int
+
+
+def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
+    """Build the plan.  CPU masks (the data-loader case) need no device synchronisation."""
+    if isinstance(ctx_mask, torch.Tensor) and ctx_mask.is_cuda:
+        ctx_np = None
+        ctx_dev = ctx_mask.to(torch.bool)
+        keep = torch.nonzero(~ctx_dev.reshape(-1)).squeeze(1).to(torch.int32)   # device sync, like the reference's x[~mask]
+        n_ctx = int(keep.numel())
+        inv = torch.full((ctx_dev.numel(),), -1, dtype=torch.int32, device=device)
+        inv[keep.long()] = torch.arange(n_ctx, dtype=torch.int32, device=device)
+        ctx_u8 = ctx_dev.to(torch.uint8).contiguous()
+        tgt_u8 = target_indices.to(torch.uint8).contiguous()
+        vis_u8 = vis_mask.to(torch.uint8).reshape(-1, vis_mask.shape[-1]).contiguous()
+        return MaskPlan(ctx_u8, tgt_u8, vis_u8, keep, inv, n_ctx)
+    ctx_np = np.ascontiguousarray(np.asarray(ctx_mask, dtype=bool))
+    tgt_np = np.ascontiguousarray(np.asarray(target_indices, dtype=bool))
+    vis_np = np.ascontiguousarray(np.asarray(vis_mask, dtype=bool))
+    keep_np = np.flatnonzero(~ctx_np.reshape(-1)).astype(np.int32)
+    inv_np = np.full(ctx_np.size, -1, dtype=np.int32)
+    inv_np[keep_np] = np.arange(keep_np.size, dtype=np.int32)
+
+    def up(a, dt):
+        return torch.from_numpy(a.astype(dt)).to(device, non_blocking=True)
+
+    return MaskPlan(up(ctx_np, np.uint8), up(tgt_np, np.uint8), up(vis_np.reshape(-1, vis_np.shape[-1]), np.uint8),
+                    up(keep_np, np.int32), up(inv_np, np.int32), int(keep_np.size))
+
+
+def conv_geometry(n_samples: int, spec) -> Tuple[List[int], List[int]]:
+    """Valid output lengths L_l and padded per-clip row counts P_l with P_{l-1} = stride_l * P_l and enough zero
+    padding rows for the dgrad taps (P_l - L_l >= ceil(k_l / s_l) - 1, at least 1)."""
+    L, cur = [], n_samples
+    for _, k, s in spec:
+        cur = (cur - k) // s + 1
+        L.append(cur)
+    n = len(spec)
+    need = [max(1, -(-spec[l][1] // spec[l][2]) - 1) for l in range(n)]
+    p_last = L[-1] + need[-1]
+    while True:
+        P = [0] * n
+        P[-1] = p_last
+        for l in range(n - 2, -1, -1):
+            P[l] = P[l + 1] * spec[l + 1][2]
+        if all(P[l] >= L[l] + need[l] for l in range(n)):
+            return L, P
+        p_last += 1
+
+
+class _Layer:
+    """Raw device pointers of one transformer layer (weights bf16, biases / LN params fp32, gradients fp32)."""
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2",
+                 "gwqkv", "gbqkv", "gwo", "gbo", "gw1", "gb1", "gw2", "gb2", "gg1", "gbe1", "gg2", "gbe2")
+
+
+def _layer_ptrs(flat: FlatParams, prefix: str, teacher: bool) -> _Layer:
+    L = _Layer()
+    names = dict(wqkv="self_attn.in_proj_weight", bqkv="self_attn.in_proj_bias", wo="self_attn.out_proj.weight",
+                 bo="self_attn.out_proj.bias", w1="linear1.weight", b1="linear1.bias", w2="linear2.weight",
+                 b2="linear2.bias", g1="norm1.weight", be1="norm1.bias", g2="norm2.weight", be2="norm2.bias")
+    for k, n in names.items():
+        full = prefix + n
+        is_w = k.startswith("w")
+        if teacher:
+            setattr(L, k, flat.tptr16(full) if is_w else flat.tptr32(full))
+            setattr(L, "g" + k, 0)
+        else:
+            setattr(L, k, flat.ptr16(full) if is_w else flat.ptr32(full))
+            setattr(L, "g" + k, flat.gptr(full))
+    return L
+
+
+class _Acts:
+    """Saved activations of one transformer layer."""
+    __slots__ = ("qkv", "o", "lse", "p", "m1", "r1", "x1", "x1b", "h", "g", "f", "m2", "r2", "x2", "x2b")
+
+
+class JepaEngine:
+    def __init__(self, cfg: EngineConfig, flat: FlatParams, pos_enc: torch.Tensor, pos_dec: torch.Tensor):
+        ops.require_gpu()
+        self.cfg, self.flat = cfg, flat
+        self.dev = flat.device
+        self.pos_enc = pos_enc.reshape(-1, cfg.d_enc).contiguous().float().to(self.dev)
+        self.pos_dec = pos_dec.reshape(-1, cfg.d_dec).contiguous().float().to(self.dev)
+        self.L, self.P = conv_geometry(cfg.n_samples, cfg.conv_spec)
+        self.T = self.L[-1]
+        self.C = cfg.conv_spec[-1][0]
+        assert all(c == self.C for c, _, _ in cfg.conv_spec), "all conv layers must have the same width"
+        assert cfg.d_enc % cfg.h_enc == 0 and cfg.d_dec % cfg.h_dec == 0
+        self.N = 0
+        self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
+        self._bind_params()
+        self._conv_w: Dict[str, torch.Tensor] = {}
+        self._alloc_conv_weights()
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def _bind_params(self) -> None:
+        f, c = self.flat, self.cfg
+        self.enc_layers = [_layer_ptrs(f, f"encoder.layers.{i}.", False) for i in range(c.l_enc)]
+        self.dec_layers = [_layer_ptrs(f, f"decoder.layers.{i}.", False) for i in range(c.l_dec)]
+        self.tea_layers = [_layer_ptrs(f, f"teacher_encoder.layers.{i}.", True) for i in range(c.l_enc)]
+
+    def _alloc_conv_weights(self) -> None:
+        C = self.C
+        for l, (_, k, s) in enumerate(self.cfg.conv_spec):
+            if l == 0:
+                continue
+            self._conv_w[f"wp{l}"] = torch.empty(C, k * C, dtype=torch.bfloat16, device=self.dev)
+            for rho in range(s):
+                U = len(range(rho, k, s))
+                if U > 0:
+                    self._conv_w[f"wd{l}_{rho}"] = torch.empty(U * C, C, dtype=torch.bfloat16, device=self.dev)
+            self._conv_w[f"dwp{l}"] = torch.zeros(C, k * C, dtype=torch.float32, device=self.dev)
+
+    def prepare_weights(self, force_cast: bool = False) -> None:
+        """bf16 shadow copies (when stale) + the GEMM layouts of conv layers 1.. from the fp32 masters."""
+        f = self.flat
+        if force_cast or not f.bf16_fresh:
+            ops.cast_f32_to_bf16(f.p32, f.p16, f.n)
+            ops.cast_f32_to_bf16(f.t32, f.t16, f.tn)
+            f.bf16_fresh = True
+        C = self.C
+        for l, (_, k, s) in enumerate(self.cfg.conv_spec):
+            if l == 0:
+                continue
+            src = f.ptr32(f"extract_audio.cnn.{l}.0.weight")
+            ops.conv_weight_layout(src, self._conv_w[f"wp{l}"], C_out=C, C_in=C, k=k, mode=0)
+            for rho in range(s):
+                U = len(range(rho, k, s))
+                if U > 0:
+                    ops.conv_weight_layout(src, self._conv_w[f"wd{l}_{rho}"], C_out=C, C_in=C, k=k, mode=1, stride=s, rho=rho, U=U)
+
+    # ------------------------------------------------------------------------------------------------ arena
+    def _rows(self, nrows: int, width: int, dtype, lead: int = 2, tail: int = 8) -> Tuple[torch.Tensor, int]:
+        """A zero-initialised [lead + nrows + tail][width] buffer; returns (tensor, pointer to row 0)."""
+        t = torch.zeros((lead + nrows + tail) * width, dtype=dtype, device=self.dev)
+        return t, t.data_ptr() + lead * width * t.element_size()
+
+    def _alloc_stack(self, M: int, D: int, H: int, B: int, layers: int) -> List[_Acts]:
+        bf, f32, dev = torch.bfloat16, torch.float32, self.dev
+        out = []
+        for _ in range(layers):
+            a = _Acts()
+            a.qkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
+            a.o = torch.empty(M, D, dtype=bf, device=dev)
+            a.lse = torch.empty(B * H * self.T, dtype=f32, device=dev)
+            a.p = torch.empty(M, D, dtype=bf, device=dev)
+            a.m1 = torch.empty(M, dtype=f32, device=dev)
+            a.r1 = torch.empty(M, dtype=f32, device=dev)
+            a.x1 = torch.empty(M, D, dtype=f32, device=dev)
+            a.x1b = torch.empty(M, D, dtype=bf, device=dev)
+            a.h = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            a.g = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            a.f = torch.empty(M, D, dtype=bf, device=dev)
+            a.m2 = torch.empty(M, dtype=f32, device=dev)
+            a.r2 = torch.empty(M, dtype=f32, device=dev)
+            a.x2 = torch.empty(M, D, dtype=f32, device=dev)
+            a.x2b = torch.empty(M, D, dtype=bf, device=dev)
+            out.append(a)
+        return out
+
+    def alloc(self, N: int, train: bool = True) -> None:
+        if N == self.N and (not train or getattr(self, "_train_alloc", False)):
+            return
+        c, bf, f32, dev = self.cfg, torch.bfloat16, torch.float32, self.dev
+        T, C, G = self.T, self.C, c.groups
+        M, Mp = N * T, N * G * T
+        self.N, self.M, self.Mp = N, M, Mp
+        self._train_alloc = train
+        nl = len(c.conv_spec)
+        # conv activations (post-GELU, and pre-GELU for layers >= 1) + their gradients
+        self.post, self.post_ptr, self.pre, self.pre_ptr = [], [], [None], [0]
+        self.dpost, self.dpost_ptr, self.dpre, self.dpre_ptr = [], [], [None], [0]
+        for l in range(nl):
+            t, p = self._rows(N * self.P[l], C, bf)
+            self.post.append(t); self.post_ptr.append(p)
+            if l > 0:
+                t, p = self._rows(N * self.P[l], C, bf)
+                self.pre.append(t); self.pre_ptr.append(p)
+            if train:
+                t, p = self._rows(N * self.P[l], C, bf)
+                self.dpost.append(t); self.dpost_ptr.append(p)
+                if l > 0:
+                    t, p = self._rows(N * self.P[l], C, bf)
+                    self.dpre.append(t); self.dpre_ptr.append(p)
+        self.gn_stats = torch.empty(2, N, C, dtype=f32, device=dev)
+        self.gn_ws = torch.empty(N, C, 2, dtype=f32, device=dev)
+        self.fn_b = torch.empty(M, C, dtype=bf, device=dev)
+        self.fn_mean = torch.empty(M, dtype=f32, device=dev)
+        self.fn_rstd = torch.empty(M, dtype=f32, device=dev)
+        self.map_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        self.lf = torch.empty(M, c.d_enc, dtype=f32, device=dev)
+        self.lf_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        # scratch stack (teacher / inference): one layer's worth, reused
+        self.scratch = self._alloc_stack(M, c.d_enc, c.h_enc, N, 1)[0]
+        self.enc_out = torch.empty(M, c.d_enc, dtype=f32, device=dev)
+        self.enc_out_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        self.enc_fm = torch.empty(M, dtype=f32, device=dev)
+        self.enc_fr = torch.empty(M, dtype=f32, device=dev)
+        if not train:
+            return
+        self.enc_acts = self._alloc_stack(M, c.d_enc, c.h_enc, N, c.l_enc)
+        self.dec_acts = self._alloc_stack(Mp, c.d_dec, c.h_dec, N * G, c.l_dec)
+        self.ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)       # gathered context rows (<= M)
+        self.cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)           # contextual_features
+        self.dec_in = torch.empty(Mp, c.d_dec, dtype=f32, device=dev)
+        self.dec_in_b = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
+        self.dec_out_b = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
+        self.dec_fm = torch.empty(Mp, dtype=f32, device=dev)
+        self.dec_fr = torch.empty(Mp, dtype=f32, device=dev)
+        self.preds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
+        self.targets = torch.empty(M, c.d_enc, dtype=f32, device=dev)
+        self.loss = torch.zeros(2, dtype=f32, device=dev)
+        self.mse_ws = torch.empty(2 + Mp, dtype=f32, device=dev)
+        # backward scratch, one set per stack width
+        self.bw = {}
+        for tag, (m, d) in dict(enc=(M, c.d_enc), dec=(Mp, c.d_dec)).items():
+            self.bw[tag] = dict(
+                dy=torch.empty(m, d, dtype=f32, device=dev), ds=torch.empty(m, d, dtype=f32, device=dev),
+                dsb=torch.empty(m, d, dtype=bf, device=dev), dh=torch.empty(m, 4 * d, dtype=bf, device=dev),
+                dx1=torch.empty(m, d, dtype=f32, device=dev), do=torch.empty(m, d, dtype=bf, device=dev),
+                dqkv=torch.empty(m, 3 * d, dtype=bf, device=dev))
+        self.dpreds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
+        self.d_cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)
+        self.d_ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        self.d_lf_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        self.d_fn = torch.empty(M, C, dtype=f32, device=dev)
+
+    # ------------------------------------------------------------------------------------------------ building blocks
+    def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
+                   mask: Optional[torch.Tensor]) -> None:
+        """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1))))."""
+        eps = self.cfg.ln_eps
+        ops.gemm(xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, lda=D, ldb=D, ldc=3 * D, bias=w.bqkv)
+        ops.attn_fwd(a.qkv, a.o, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, lse=a.lse)
+        ops.gemm(a.o, w.wo, a.p, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, bias=w.bo)
+        ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1)
+        ops.gemm(a.x1b, w.w1, a.h, C2=a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2)
+        ops.gemm(a.g, w.w2, a.f, M=M, N=D, K=4 * D, lda=4 * D, ldb=4 * D, ldc=D, bias=w.b2)
+        ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2, y_bf16=a.x2b, mean=a.m2, rstd=a.r2)
+
+    def _wgrad(self, dY, X, gW, n_out: int, k_in: int, m_tok: int) -> None:
+        """gW[n_out, k_in] += dY[m_tok, n_out]^T @ X[m_tok, k_in]"""
+        ops.gemm(dY, X, gW, M=n_out, N=k_in, K=m_tok, lda=n_out, ldb=k_in, ldc=k_in, a_trans=1, b_trans=1,
+                 epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(n_out, k_in, m_tok))
+
+    def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dx_out: torch.Tensor,
+                   M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict) -> None:
+        """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer."""
+        ds, dsb, dh, dx1, do, dqkv = bw["ds"], bw["dsb"], bw["dh"], bw["dx1"], bw["do"], bw["dqkv"]
+        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2)
+        self._wgrad(dsb, a.g, w.gw2, D, 4 * D, M)
+        ops.gemm(dsb, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h)
+        ops.colsum_bf16(dh, w.gb1, M=M, N=4 * D, ldx=4 * D)
+        self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
+        ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
+        ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo)
+        self._wgrad(dsb, a.o, w.gwo, D, D, M)
+        ops.gemm(dsb, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+        ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask)
+        ops.colsum_bf16(dqkv, w.gbqkv, M=M, N=3 * D, ldx=3 * D)
+        self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, M)
+        ops.gemm(dqkv, w.wqkv, dx_out, M=M, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
+
+    # ------------------------------------------------------------------------------------------------ front-end
+    def _frontend(self, audio: torch.Tensor) -> None:
+        """audio bf16 [N, C_in, L] -> lf (fp32) / lf_b (bf16) [N*T, d_enc]   (reference jepa.py:391-396)"""
+        c, f, N, C = self.cfg, self.flat, self.N, self.C
+        _, k0, s0 = c.conv_spec[0]
+        ops.conv0_fwd(audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
+                      f.ptr32("extract_audio.cnn.0.2.bias"), self.post_ptr[0], self.gn_stats[0], self.gn_stats[1], self.gn_ws,
+                      N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0])
+        for l in range(1, len(c.conv_spec)):
+            _, k, s = c.conv_spec[l]
+            ops.gemm(self.post_ptr[l - 1], self._conv_w[f"wp{l}"], self.pre_ptr[l], C2=self.post_ptr[l], M=N * self.P[l], N=C,
+                     K=k * C, lda=s * C, ldb=k * C, ldc=C, epilogue=ops.EPI_CONV_GELU, seg_rows=self.P[l], seg_valid=self.L[l])
+        M, T = self.M, self.T
+        ops.layernorm_fwd(self.post_ptr[-1], f.ptr32("feature_norms.weight"), f.ptr32("feature_norms.bias"), M=M, D=C,
+                          eps=c.norm_eps, y_bf16=self.fn_b, mean=self.fn_mean, rstd=self.fn_rstd, x_is_bf16=True,
+                          in_seg=self.P[-1], in_valid=T)
+        if self.has_mapper:
+            ops.gemm(self.fn_b, f.ptr16("post_extraction_mapper.weight"), self.map_b, M=M, N=c.d_enc, K=C, lda=C, ldb=C,
+                     ldc=c.d_enc, bias=f.ptr32("post_extraction_mapper.bias"))
+            src = self.map_b
+        else:
+            src = self.fn_b
+        ops.add_pos(src, self.pos_enc, M=M, T=T, D=c.d_enc, y_f32=self.lf, y_bf16=self.lf_b)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, audio: torch.Tensor, plan: MaskPlan) -> None:
+        """Training forward.  Results: self.loss[0], self.preds, self.targets, self.cf[:n_ctx], self.lf."""
+        c, f = self.cfg, self.flat
+        N = audio.shape[0]
+        self.alloc(N, train=True)
+        self.plan = plan
+        self.audio = audio
+        M, Mp, T, G = self.M, self.Mp, self.T, c.groups
+        De, Dd = c.d_enc, c.d_dec
+        self._frontend(audio)
+        # student encoder (keys restricted to the context)
+        x, xb = self.lf, self.lf_b
+        for w, a in zip(self.enc_layers, self.enc_acts):
+            self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, plan.ctx_u8)
+            x, xb = a.x2, a.x2b
+        ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=M, D=De, eps=c.norm_eps,
+                          y_f32=self.enc_out, y_bf16=self.enc_out_b, mean=self.enc_fm, rstd=self.enc_fr)
+        n_ctx = plan.n_ctx
+        ops.mask_gather_rows(self.enc_out_b, plan.keep, self.ctx_in, n_rows=n_ctx, D=De, elem_bytes=2)
+        ops.gemm(self.ctx_in, f.ptr16("encoder_to_decoder_mapper.weight"), self.cf, M=n_ctx, N=Dd, K=De, lda=De, ldb=De, ldc=Dd,
+                 bias=f.ptr32("encoder_to_decoder_mapper.bias"))
+        # predictor over (context U group targets), one batch row per (clip, group)
+        ops.mask_scatter_fill_pos(self.cf, plan.inv, f.ptr32("mask_token"), self.pos_dec, B=N, T=T, D=Dd, G=G,
+                                  out_f32=self.dec_in, out_bf16=self.dec_in_b)
+        x, xb = self.dec_in, self.dec_in_b
+        for w, a in zip(self.dec_layers, self.dec_acts):
+            self._layer_fwd(w, a, x, xb, Mp, Dd, c.h_dec, N * G, plan.vis_u8)
+            x, xb = a.x2, a.x2b
+        ops.layernorm_fwd(x, f.ptr32("decoder.norm.weight"), f.ptr32("decoder.norm.bias"), M=Mp, D=Dd, eps=c.norm_eps,
+                          y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr)
+        ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Mp, N=De, K=Dd, lda=Dd, ldb=Dd,
+                 ldc=De, bias=f.ptr32("decoder_to_encoder_mapper.bias"))
+        # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of last k layers
+        self._teacher_targets()
+        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=N, G=G, T=T, D=De)
+
+    def _teacher_targets(self) -> None:
+        c, N, M, De = self.cfg, self.N, self.M, self.cfg.d_enc
+        a = self.scratch
+        x, xb = self.lf, self.lf_b
+        kept = 0
+        for i, w in enumerate(self.tea_layers):
+            self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None)
+            # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
+            # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
+            x, xb = a.x2, a.x2b
+            if c.l_enc - i <= c.top_k:
+                if c.top_k > 1:
+                    ops.instnorm_accumulate(x, self.targets, B=N, TD=self.T * De, accumulate=kept > 0, scale=1.0 / c.top_k)
+                kept += 1
+        if c.top_k <= 1:
+            self.targets.copy_(x)
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def backward(self, gscale_ptr: int = 0, on_grads_ready=None) -> None:
+        """Gradients of self.loss[0] w.r.t. every trainable parameter -> flat.g32 (overwritten).
+
+        `on_grads_ready(tag)` is called (host side, stream-ordered) as sections of the flat gradient buffer become
+        final: "dec" (predictor + both mappers), "enc:<i>" after encoder layer i, "front" at the end -- the hook the
+        data-parallel wrapper uses to launch bucketed RCCL all-reduces that overlap the rest of the backward."""
+        ready = on_grads_ready if on_grads_ready is not None else (lambda tag: None)
+        c, f, plan = self.cfg, self.flat, self.plan
+        N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, c.groups, self.C
+        De, Dd = c.d_enc, c.d_dec
+        f.g32.zero_()
+        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=N, G=G, T=T, D=De, dpreds=self.dpreds,
+                       gscale_ptr=gscale_ptr if gscale_ptr else None)
+        bw = self.bw["dec"]
+        # decoder_to_encoder_mapper
+        ops.colsum_bf16(self.dpreds, f.gptr("decoder_to_encoder_mapper.bias"), M=Mp, N=De, ldx=De)
+        self._wgrad(self.dpreds, self.dec_out_b, f.gptr("decoder_to_encoder_mapper.weight"), De, Dd, Mp)
+        ops.gemm(self.dpreds, f.ptr16("decoder_to_encoder_mapper.weight"), bw["dx1"], M=Mp, N=Dd, K=De, lda=De, ldb=Dd, ldc=Dd,
+                 b_trans=1, epilogue=ops.EPI_ADD_F32)
+        last = self.dec_acts[-1]
+        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Mp, D=Dd, ds_f32=bw["dy"],
+                          dgamma=f.gptr("decoder.norm.weight"), dbeta=f.gptr("decoder.norm.bias"))
+        dy = bw["dy"]
+        for i in range(c.l_dec - 1, -1, -1):
+            x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
+            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Mp, Dd, c.h_dec, N * G, plan.vis_u8, bw)
+        n_ctx = plan.n_ctx
+        ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G)
+        # encoder_to_decoder_mapper (rows = gathered context tokens)
+        ops.colsum_bf16(self.d_cf, f.gptr("encoder_to_decoder_mapper.bias"), M=n_ctx, N=Dd, ldx=Dd)
+        self._wgrad(self.d_cf, self.ctx_in, f.gptr("encoder_to_decoder_mapper.weight"), Dd, De, n_ctx)
+        ops.gemm(self.d_cf, f.ptr16("encoder_to_decoder_mapper.weight"), self.d_ctx_in, M=n_ctx, N=De, K=Dd, lda=Dd, ldb=De,
+                 ldc=De, b_trans=1)
+        ready("dec")
+        bw = self.bw["enc"]
+        ops.unmask_rows_f32(self.d_ctx_in, plan.inv, bw["dx1"], M=M, D=De)
+        last = self.enc_acts[-1]
+        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("encoder.norm.weight"), self.enc_fm, self.enc_fr, M=M, D=De, ds_f32=bw["dy"],
+                          dgamma=f.gptr("encoder.norm.weight"), dbeta=f.gptr("encoder.norm.bias"))
+        dy = bw["dy"]
+        for i in range(c.l_enc - 1, -1, -1):
+            x_in, xb_in = (self.lf, self.lf_b) if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
+            self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, M, De, c.h_enc, N, plan.ctx_u8, bw)
+            ready(f"enc:{i}")
+        # dy = d(local_features) fp32.  The teacher branch is detached (jepa.py:408).
+        ops.cast_f32_to_bf16(dy, self.d_lf_b, M * De)
+        if self.has_mapper:
+            ops.colsum_bf16(self.d_lf_b, f.gptr("post_extraction_mapper.bias"), M=M, N=De, ldx=De)
+            self._wgrad(self.d_lf_b, self.fn_b, f.gptr("post_extraction_mapper.weight"), De, C, M)
+            ops.gemm(self.d_lf_b, f.ptr16("post_extraction_mapper.weight"), self.d_fn, M=M, N=C, K=De, lda=De, ldb=C, ldc=C,
+                     b_trans=1, epilogue=ops.EPI_ADD_F32)
+            d_fn = self.d_fn
+        else:
+            d_fn = dy
+        nl = len(c.conv_spec)
+        ops.layernorm_bwd(d_fn, self.post_ptr[-1], f.ptr32("feature_norms.weight"), self.fn_mean, self.fn_rstd, M=M, D=C,
+                          ds_bf16=self.dpost_ptr[-1], dgamma=f.gptr("feature_norms.weight"), dbeta=f.gptr("feature_norms.bias"),
+                          x_is_bf16=True, in_seg=self.P[-1], in_valid=T, out_seg=self.P[-1], out_valid=T)
+        for l in range(nl - 1, 0, -1):
+            _, k, s = c.conv_spec[l]
+            rows = N * self.P[l]
+            ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], rows * C)
+            dwp = self._conv_w[f"dwp{l}"]
+            dwp.zero_()
+            ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=rows, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
+                     b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, rows))
+            ops.conv_weight_layout(dwp, f.gptr(f"extract_audio.cnn.{l}.0.weight"), C_out=C, C_in=C, k=k, mode=2)
+            empty_phase = any(len(range(rho, k, s)) == 0 for rho in range(s))
+            if empty_phase:
+                self.dpost[l - 1].zero_()
+            for rho in range(s):
+                U = len(range(rho, k, s))
+                if U == 0:
+                    continue
+                ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
+                         M=rows, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1)
+        _, k0, s0 = c.conv_spec[0]
+        ops.conv0_bwd(self.audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
+                      f.ptr32("extract_audio.cnn.0.2.bias"), self.gn_stats[0], self.gn_stats[1], self.dpost_ptr[0],
+                      f.gptr("extract_audio.cnn.0.0.weight"), f.gptr("extract_audio.cnn.0.2.weight"),
+                      f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws, N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0,
+                      stride=s0, L_out=self.L[0], P=self.P[0])
+        ready("front")
+
+    # ------------------------------------------------------------------------------------------------ EMA / inference
+    def ema_step(self, r: float) -> None:
+        f = self.flat
+        ops.ema_update(f.p32.data_ptr() + 4 * f.enc_offset, f.t32, f.enc_numel, r, teacher_bf16=f.t16)
+
+    def infer(self, audio: torch.Tensor, key_mask_u8: Optional[torch.Tensor]) -> torch.Tensor:
+        """Student-only forward (reference jepa.py:456-467): returns fp32 [N, T, d_enc]."""
+        c, f = self.cfg, self.flat
+        N = audio.shape[0]
+        if N != self.N:
+            self.alloc(N, train=False)
+        self._frontend(audio)
+        a = self.scratch
+        x, xb = self.lf, self.lf_b
+        for w in self.enc_layers:
+            self._layer_fwd(w, a, x, xb, self.M, c.d_enc, c.h_enc, N, key_mask_u8)
+            x, xb = a.x2, a.x2b
+        ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=self.M, D=c.d_enc, eps=c.norm_eps,
+                          y_f32=self.enc_out)
+        return self.enc_out.view(N, self.T, c.d_enc)

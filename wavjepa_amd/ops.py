@@ -161,9 +161,9 @@ def instnorm_accumulate(x: Ptr, targets: Ptr, *, B: int, TD: int, accumulate: bo
 
 
 def masked_mse(preds: Ptr, targets: Ptr, tgt: Ptr, loss: Ptr, workspace: Ptr, *, B: int, G: int, T: int, D: int,
-               dpreds: Ptr = None, gscale: float = 1.0, stream: Optional[int] = None) -> None:
+               dpreds: Ptr = None, gscale: float = 1.0, gscale_ptr: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_masked_mse", "wj_mse_args", stream, preds=_p(preds), targets=_p(targets), tgt=_p(tgt), loss=_p(loss),
-         dpreds=_p(dpreds), workspace=_p(workspace), B=B, G=G, T=T, D=D, gscale=gscale)
+         dpreds=_p(dpreds), workspace=_p(workspace), gscale_ptr=_p(gscale_ptr), B=B, G=G, T=T, D=D, gscale=gscale)
 
 
 # ---------------------------------------------------------------------------------------------------------- optimiser side
