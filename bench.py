@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WavJEPA pre-training clips/s on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the whole optimisation step on every rank's own 256 synthetic clips (32 white-noise 10 s sources x 8
+random 2.01 s crops @16 kHz): crop + normalise, conv encoder, student ViT, predictor, EMA-teacher targets, masked MSE,
+EMA update, full backward, gradient all-reduce (N > 1), global-norm clip, AdamW.  WavJEPA-base (12 x d768 student and
+teacher, 12 x d384 predictor, 512-ch conv stack), bf16 compute with fp32 master weights, random-init weights.
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline     the dominant kernel of the step (the bf16 MFMA GEMM family), ALGORITHMIC flops / measured duration, both
+               taken live from an instrumented step of this very run (HIP events on the launch stream around every
+               C-ABI call), against the dense bf16 MFMA peak of MI355X (2.5 PFLOP/s);
+  cpu_baseline the CPU oracle (a port of the reference's algorithm, `oracle/`) timed on this host's cores on a bounded
+               sample (N=2 clips, base model, fp32, <= 32 threads, ~25 s budget) -- a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONV_SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)]
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; /opt/skills/guides/MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
+STEP_GFLOP_PER_CLIP = 283.7      # dense algorithmic FLOPs of one step per clip (fwd 118.2 + bwd 165.5)
+
+
+def build_model(device, seed: int):
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.jepa import JEPA
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    torch.manual_seed(seed)
+    ext = ConvFeatureExtractor(conv_layers_spec=CONV_SPEC, in_channels=1)
+    model = JEPA(feature_extractor=ext, transformer_encoder_cfg=TransformerEncoderCFG.create(),
+                 transformer_encoder_layers_cfg=TransformerLayerCFG.create(), transformer_decoder_cfg=TransformerEncoderCFG.create(),
+                 transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384), lr=4e-4, adam_betas=(0.9, 0.98),
+                 adam_weight_decay=0.04, resample_sr=16000, process_audio_seconds=2.01, nr_samples_per_audio=8,
+                 average_top_k_layers=8, size="base")
+    return model.to(device)
+
+
+def gemm_kernel_name(f) -> str:
+    epi = {0: "BF16", 1: "BIAS_GELU2", 2: "MUL_GELU_GRAD", 3: "ADD_F32", 4: "ATOMIC_F32", 5: "CONV_GELU"}[f["epilogue"]]
+    return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
+
+
+def profile_one_step(runner, source, step_idx: int):
+    """Run one extra step with every C-ABI call bracketed by HIP events; returns per-kernel-class totals."""
+    from wavjepa_amd import ops
+    ops.PROFILE = []
+    try:
+        runner.step(source.next_batch(), step_idx)
+        torch.cuda.synchronize()
+        recs = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    classes = {}
+    for fn, f, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        if fn == "wj_gemm_bf16":
+            name, flops = gemm_kernel_name(f), 2.0 * f["M"] * f["N"] * f["K"]
+        else:
+            name, flops = fn, 0.0
+        c = classes.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+        c["ms"] += ms
+        c["flops"] += flops
+        c["launches"] += 1
+    return classes
+
+
+def cpu_baseline(n_clips: int = 2, budget_s: float = 25.0, max_threads: int = 32):
+    """The oracle's full train step (fp32) on the host cores -- a port of the reference algorithm, kind='port'.
+    Bounded: at most ~budget_s seconds of CPU work after the first (warm-up) step."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    from oracle import jepa_oracle as J
+    from oracle import masking_oracle as M
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, max_threads))
+    torch.set_num_threads(cores)
+    shapes = synth.jepa_shapes(conv_spec=CONV_SPEC, in_channels=1, d_enc=768, enc_layers=12, d_dec=384, dec_layers=12, n_tokens=200)
+    g = torch.Generator().manual_seed(0)
+    P = {}
+    for k, shp in shapes.items():
+        if k.startswith("pos_encoding_"):
+            continue
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k.endswith("norm.weight") or k.endswith("norms.weight") or k.endswith("cnn.0.2.weight"):
+            P[k] = torch.ones(shp)
+        elif k.endswith("bias"):
+            P[k] = torch.zeros(shp)
+        else:
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+            P[k] = torch.randn(shp, generator=g) * (1.0 / max(1, fan_in)) ** 0.5
+    P["pos_encoding_encoder"] = J.sincos_positions(768, 200)
+    P["pos_encoding_decoder"] = J.sincos_positions(384, 200)
+    rng = np.random.default_rng(0)
+    ctx, tgt, vis = M.time_inverse_block_masks(n_clips, 200, 1, new_rng=lambda: np.random.default_rng(rng.integers(1 << 31)))
+    batch = (torch.randn(n_clips, 1, 32159, generator=g), torch.from_numpy(ctx), torch.from_numpy(tgt), torch.from_numpy(vis))
+    state = {}
+    t0 = time.perf_counter()
+    J.train_step(P, state, 0, batch, mode="fp32")
+    first = time.perf_counter() - t0
+    times = []
+    while sum(times) + first < budget_s and len(times) < 5:
+        t0 = time.perf_counter()
+        J.train_step(P, state, 1 + len(times), batch, mode="fp32")
+        times.append(time.perf_counter() - t0)
+    dt = (sum(times) / len(times)) if times else first
+    return dict(value=round(n_clips / dt, 3), unit="clips/s", cores=cores, kind="port",
+                sample=f"oracle train step (fwd+EMA+bwd+clip+AdamW), WavJEPA-base, N={n_clips} clips, fp32, {cores} threads of {avail} "
+                       f"available, 1 warm-up + {len(times)} timed steps, {dt * 1000:.0f} ms/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clips-per-gpu", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    from wavjepa_amd.data import SyntheticAudioSource
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    from wavjepa_amd.trainer import StepRunner, init_distributed
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local)
+    S = 8
+    if args.clips_per_gpu % S:
+        raise SystemExit("--clips-per-gpu must be a multiple of 8 (8 crops per source audio)")
+    model = build_model(device, seed=42)          # same init on every rank (+ broadcast from rank 0 in StepRunner)
+    model.trainer.max_steps = 375000
+    masker = TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10, target_prob=0.25,
+                                    target_length=10, ratio_cutoff=0.1)      # configs/masker/AudioSet.yaml
+    source = SyntheticAudioSource(masker, batch_size=args.clips_per_gpu // S, samples_per_audio=S, n_tokens=model.total_patches,
+                                  seed=42 + rank, n_mask_sets=8, device=device)
+    runner = StepRunner(model, gradient_clip_val=5.0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    step_idx = 0
+    for _ in range(args.warmup):
+        runner.step(source.next_batch(), step_idx)
+        step_idx += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = runner.step(source.next_batch(), step_idx)
+        step_idx += 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(out["loss"].detach())
+    if not (loss == loss):
+        raise SystemExit("loss is NaN")
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note(f"timed region done: {elapsed / args.steps * 1000:.1f} ms/step")
+    roofline = None
+    classes = {}
+    if not args.no_profile:
+        classes = profile_one_step(runner, source, step_idx)
+        gemms = {k: v for k, v in classes.items() if v["flops"] > 0}
+        if gemms:
+            name, c = max(gemms.items(), key=lambda kv: kv[1]["ms"])
+            all_ms = sum(v["ms"] for v in gemms.values())
+            all_fl = sum(v["flops"] for v in gemms.values())
+            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, launches_per_step=c["launches"],
+                            avg_launch_ms=round(c["ms"] / c["launches"], 4),
+                            gflop_per_launch=round(c["flops"] / c["launches"] / 1e9, 2),
+                            all_gemm_achieved=round(all_fl / (all_ms * 1e-3) / 1e12, 1),
+                            gemm_share_of_step=round(all_ms / sum(v["ms"] for v in classes.values()), 3))
+
+    if rank == 0:
+        clips = args.clips_per_gpu * world * args.steps
+        value = clips / elapsed
+        line = {
+            "metric": "jepa_pretrain_clips_per_sec", "value": round(value, 1), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1000, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "WavJEPA-base JEPA pre-training step, 2.01 s @16 kHz white-noise clips (32159 samples -> 200 tokens), "
+                                   f"{args.clips_per_gpu} clips per GPU (32 sources x 8 crops), AudioSet masker, random-init weights",
+                       "global_batch": args.clips_per_gpu * world, "seq_len": 200, "parallelism": f"dp{world}",
+                       "step_gflop_per_clip": STEP_GFLOP_PER_CLIP},
+            "model_tflops_per_gpu": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1),
+            "final_loss": round(loss, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            note("instrumented step done; timing the CPU oracle")
+            line["cpu_baseline"] = cpu_baseline()
+            note("cpu baseline done")
+        print(json.dumps(line), flush=True)
+        if classes:
+            top = sorted(classes.items(), key=lambda kv: -kv[1]["ms"])[:25]
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_classes.json"), "w") as fh:
+                json.dump({k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None) for k, v in top}, fh, indent=1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""Synthetic input source for benchmarking / smoke training: white-noise 10 s sources generated on the device and
+pre-generated CPU masks that are cycled (so the NumPy masker -- ~0.6 ms per clip -- is not on the timed path).
+
+Stands in for reference data_modules/WebAudioDataModule.py:43-142 (webdataset shards -> resample -> RMS-normalise ->
+10 s pad -> masker); the batch layout is the same: (audio [B,1,L_full] f32, ctx [B,S,T], tgt [B,S,G,T], vis [B,S,G,T])."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from .engine import MaskPlan, make_mask_plan
+
+
+class SyntheticAudioSource:
+    def __init__(self, masker, *, batch_size: int = 32, samples_per_audio: int = 8, n_tokens: int = 200, in_channels: int = 1,
+                 sr: int = 16000, seconds: float = 10.0, seed: int = 42, n_mask_sets: int = 16, device=None):
+        self.B, self.S, self.T, self.C = batch_size, samples_per_audio, n_tokens, in_channels
+        self.L_full = int(sr * seconds)
+        self.device = device
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+        self.mask_sets: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []
+        for _ in range(n_mask_sets):
+            ctx, tgt, vis = masker(batch_size=batch_size * samples_per_audio, n_times=n_tokens, in_channels=in_channels)
+            self.mask_sets.append((ctx.view(batch_size, samples_per_audio, -1), tgt.view(batch_size, samples_per_audio, *tgt.shape[1:]),
+                                   vis.view(batch_size, samples_per_audio, *vis.shape[1:])))
+        self._i = 0
+
+    def next_batch(self):
+        audio = torch.randn(self.B, self.C, self.L_full, generator=self.gen, device=self.device, dtype=torch.float32)
+        ctx, tgt, vis = self.mask_sets[self._i % len(self.mask_sets)]
+        self._i += 1
+        return audio, ctx, tgt, vis
+
+    def __iter__(self):
+        while True:
+            yield self.next_batch()

@@ -1,0 +1,83 @@
+"""Data parallelism for the flat-gradient engine: one process per GPU, RCCL all-reduce (average) of the flat fp32
+gradient buffer in a few large contiguous buckets, launched from the backward's section hooks so that the predictor /
+encoder buckets travel over xGMI while the rest of the backward (encoder layers, conv stack) still computes.
+
+Replaces Lightning's `strategy="ddp"` (reference train.py:174-179): same semantics -- every rank normalises its loss by
+its LOCAL target count and the gradients are averaged with equal rank weights -- without per-tensor hooks
+or 25 MB autograd buckets: xGMI is point-to-point (7 links/GPU), so fewer, larger collectives are the better fit.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .params import FlatParams
+
+
+def section_ranges(flat: FlatParams, enc_layers: int, enc_chunk: int = 3) -> Dict[str, List[Tuple[int, int]]]:
+    """Map the engine's backward tags to contiguous [lo, hi) ranges of the flat gradient buffer."""
+    def span(prefixes) -> Tuple[int, int]:
+        sl = [s for s in flat.slots if any(s.name.startswith(p) for p in prefixes)]
+        lo = min(s.offset for s in sl)
+        hi = max(s.offset + (s.numel + 7) // 8 * 8 for s in sl)
+        return lo, hi
+
+    out: Dict[str, List[Tuple[int, int]]] = {}
+    out["dec"] = [span(["decoder.", "decoder_to_encoder_mapper.", "encoder_to_decoder_mapper."])]
+    # encoder layers are final in descending order; ship them in chunks of `enc_chunk` layers when the lowest is done
+    hi_layer = enc_layers - 1
+    while hi_layer >= 0:
+        lo_layer = max(0, hi_layer - enc_chunk + 1)
+        prefixes = [f"encoder.layers.{i}." for i in range(lo_layer, hi_layer + 1)]
+        if hi_layer == enc_layers - 1:
+            prefixes.append("encoder.norm.")
+        out[f"enc:{lo_layer}"] = [span(prefixes)]
+        hi_layer = lo_layer - 1
+    front = [span(["mask_token", "extract_audio.", "feature_norms."])]
+    if any(s.name.startswith("post_extraction_mapper.") for s in flat.slots):
+        front.append(span(["post_extraction_mapper."]))
+    out["front"] = front
+    covered = sorted(r for v in out.values() for r in v)
+    pos = 0
+    for lo, hi in covered:
+        assert lo == pos, "gradient buckets must tile the flat buffer"
+        pos = hi
+    assert pos == flat.n
+    return out
+
+
+class FlatGradAllReducer:
+    def __init__(self, module, process_group=None, enc_chunk: int = 3):
+        self.module = module
+        self.pg = process_group
+        self.enc_chunk = enc_chunk
+        self.handles: List = []
+        self._ranges: Optional[Dict[str, List[Tuple[int, int]]]] = None
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+
+    def broadcast_parameters(self) -> None:
+        """Rank 0's student, teacher and optimiser-visible state to everyone (DDP constructor broadcast)."""
+        if self.world == 1:
+            return
+        self.module._ensure_engine()
+        flat = self.module._flat
+        dist.broadcast(flat.p32, 0, group=self.pg)
+        dist.broadcast(flat.t32, 0, group=self.pg)
+        self.module._student_bf16_fresh = False
+        self.module._teacher_bf16_fresh = False
+
+    def hook(self, tag: str) -> None:
+        if self.world == 1:
+            return
+        flat = self.module._flat
+        if self._ranges is None:
+            self._ranges = section_ranges(flat, self.module.encoder.num_layers, self.enc_chunk)
+        for lo, hi in self._ranges.get(tag, []):
+            self.handles.append(dist.all_reduce(flat.g32[lo:hi], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+
+    def wait(self) -> None:
+        for h in self.handles:
+            h.wait()          # stream-level dependency; does not block the host
+        self.handles = []

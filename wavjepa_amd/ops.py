@@ -35,11 +35,24 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# When set to a list, every call is bracketed by HIP events on the launch stream (bench.py's live per-kernel timing):
+# entries are (entry point, fields, start_event, end_event).  None (default) = zero overhead.
+PROFILE = None
+
+
 def _run(fn: str, struct_name: str, stream: Optional[int], **fields) -> None:
     a = STRUCTS[struct_name]()
     for k, v in fields.items():
         setattr(a, k, v)
-    _abi.call(fn, a, _stream() if stream is None else stream)
+    if PROFILE is None:
+        _abi.call(fn, a, _stream() if stream is None else stream)
+        return
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    _abi.call(fn, a, s.cuda_stream)
+    e1.record(s)
+    PROFILE.append((fn, fields, e0, e1))
 
 
 def require_gpu() -> None:

@@ -1,0 +1,120 @@
+"""Minimal trainer with the slice of pytorch_lightning.Trainer's behaviour the reference relies on
+(reference train.py:160-180,244): one process per GPU, bf16 compute (the kernels' native flow), gradient-norm clipping
+at `gradient_clip_val`, per-step LR scheduler, EMA inside training_step, periodic checkpoints with the
+Lightning checkpoint keys (`state_dict`, `hyper_parameters`, `global_step`)."""
+from __future__ import annotations
+
+import os
+import time
+from typing import Any, Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .ddp import FlatGradAllReducer
+
+
+def init_distributed() -> tuple:
+    """(rank, local_rank, world).  RCCL ("nccl" backend on ROCm) when launched by torch.distributed.run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+class StepRunner:
+    """One optimisation step in the reference's order."""
+
+    def __init__(self, model, gradient_clip_val: float = 5.0, enc_chunk: int = 3):
+        self.model = model
+        model._ensure_engine()
+        self.reducer = FlatGradAllReducer(model, enc_chunk=enc_chunk)
+        self.reducer.broadcast_parameters()
+        model._grads_ready_hook = self.reducer.hook
+        oc = model.configure_optimizers()
+        self.optimizer = oc["optimizer"]
+        self.scheduler = oc["lr_scheduler"]["scheduler"]
+        self.optimizer.max_grad_norm = float(gradient_clip_val or 0.0)
+
+    def step(self, raw_batch, batch_idx: int) -> Dict[str, Any]:
+        m = self.model
+        batch = m.on_after_batch_transfer(raw_batch, 0)     # crops + normalise + bf16 on the device
+        out = m.training_step(batch, batch_idx)             # forward + EMA of the teacher
+        out["loss"].backward()                              # engine backward; buckets all-reduce as they complete
+        self.reducer.wait()
+        self.optimizer.step()                               # fused global-norm clip + AdamW over the flat buffers
+        self.scheduler.step()
+        m.global_step += 1
+        return out
+
+
+class Trainer:
+    def __init__(self, accelerator: str = "gpu", max_steps: int = 375000, max_epochs: int = -1, precision: str = "bf16-mixed",
+                 devices: int = 1, gradient_clip_val: float = 5.0, gradient_clip_algorithm: str = "norm", strategy: str = "auto",
+                 log_every_n_steps: int = 50, default_root_dir: Optional[str] = None, checkpoint_every_n_steps: int = 25000,
+                 **unused):
+        if accelerator not in ("gpu", "cuda", "auto"):
+            raise ValueError("wavjepa_amd trains on MI355X GPUs only (accelerator='gpu'); there is no CPU path")
+        if precision not in ("bf16-mixed", "bf16"):
+            raise ValueError("the HIP path computes in bf16 with fp32 master weights (precision='bf16-mixed')")
+        if gradient_clip_algorithm != "norm":
+            raise ValueError("only norm clipping is implemented")
+        self.max_steps = int(max_steps)
+        self.devices = int(devices)
+        self.gradient_clip_val = gradient_clip_val
+        self.log_every_n_steps = log_every_n_steps
+        self.root = default_root_dir
+        self.ckpt_every = checkpoint_every_n_steps
+        self.rank, self.local_rank, self.world = init_distributed()
+        self.logged: Dict[str, Any] = {}
+
+    def log_dict(self, data: Dict[str, Any], **kw) -> None:
+        self.logged = data          # kept on the device: no per-step host sync / scalar all-reduce
+
+    def save_checkpoint(self, model, runner: StepRunner, path: str) -> None:
+        if self.rank != 0:
+            return
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                    "hyper_parameters": dict(model.hparams), "global_step": model.global_step,
+                    "optimizer": runner.optimizer.state_dict(), "lr_scheduler": runner.scheduler.state_dict()}, path)
+
+    def fit(self, model, datamodule=None, train_dataloaders: Optional[Iterable] = None, ckpt_path: Optional[str] = None):
+        dev = torch.device("cuda", self.local_rank)
+        model.to(dev)
+        model.trainer = self
+        model.train()
+        runner = StepRunner(model, self.gradient_clip_val)
+        if ckpt_path:
+            ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+            model.load_state_dict(ck["state_dict"])
+            model.global_step = int(ck.get("global_step", 0))
+            if "optimizer" in ck:
+                runner.optimizer.load_state_dict(ck["optimizer"])
+            if "lr_scheduler" in ck:
+                runner.scheduler.load_state_dict(ck["lr_scheduler"])
+        loader = train_dataloaders if train_dataloaders is not None else datamodule.train_dataloader()
+        t0 = time.time()
+        for batch in loader:
+            if model.global_step >= self.max_steps:
+                break
+            out = runner.step(batch, model.global_step)
+            gs = model.global_step
+            if self.log_every_n_steps and gs % self.log_every_n_steps == 0 and self.rank == 0:
+                loss = float(out["loss"])          # the only host sync, every n steps
+                dt = time.time() - t0
+                print(f"step {gs}  loss {loss:.5f}  lr {runner.scheduler.get_last_lr()[0]:.3e}  ema {model._get_ema_decay():.6f}  "
+                      f"{dt / self.log_every_n_steps * 1000:.1f} ms/step", flush=True)
+                t0 = time.time()
+            if self.root and self.ckpt_every and gs % self.ckpt_every == 0:
+                self.save_checkpoint(model, runner, os.path.join(self.root, f"step={gs}.ckpt"))
+        if self.root:
+            self.save_checkpoint(model, runner, os.path.join(self.root, "last.ckpt"))
+        return runner
