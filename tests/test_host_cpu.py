@@ -1,0 +1,237 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol with matching struct layouts,
+maskers / positions reproduce the reference fixtures, module + state_dict layout, config loader, conv geometry,
+gradient-bucket tiling, and the product path's refusal to run without a GPU (no silent fallback)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)]
+SMALL_SPEC = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)]
+
+
+def small_model(**kw):
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.jepa import JEPA
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    ext = ConvFeatureExtractor(conv_layers_spec=SMALL_SPEC, in_channels=1)
+    return JEPA(feature_extractor=ext, transformer_encoder_cfg=TransformerEncoderCFG.create(num_layers=3),
+                transformer_encoder_layers_cfg=TransformerLayerCFG.create(d_model=128, nhead=2),
+                transformer_decoder_cfg=TransformerEncoderCFG.create(num_layers=2),
+                transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=64, nhead=2), average_top_k_layers=2,
+                process_audio_seconds=2.01, nr_samples_per_audio=2, **kw)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from wavjepa_amd import _abi
+    lib = _abi.load()
+    assert lib.wj_abi_version() == 1
+    assert len(_abi.FUNCTIONS) >= 25
+    for fn in _abi.FUNCTIONS:
+        assert hasattr(lib, fn), fn
+    for name, cls in _abi.STRUCTS.items():
+        assert lib.wj_struct_size(name.encode()) == ctypes.sizeof(cls), name
+    assert lib.wj_struct_size(b"no_such_struct") == -1
+    assert lib.wj_device_count() >= 0
+
+
+def test_abi_rejects_bad_arguments_without_a_gpu():
+    """Argument validation happens before any launch, so it can be exercised on a CPU-only host."""
+    from wavjepa_amd import _abi
+    lib = _abi.load()
+    a = _abi.STRUCTS["wj_gemm_args"]()
+    assert lib.wj_gemm_bf16(ctypes.byref(a), None) == -1            # null pointers
+    a.A = a.B = a.C = 16
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldc = 8, 12, 8, 8, 8, 12           # N % 8 != 0
+    assert lib.wj_gemm_bf16(ctypes.byref(a), None) == -1
+    b = _abi.STRUCTS["wj_attn_fwd_args"]()
+    b.qkv = b.out = 16
+    b.B, b.T, b.H, b.hd, b.mask_group = 1, 300, 2, 64, 1              # T > 224
+    assert lib.wj_attn_fwd(ctypes.byref(b), None) == -1
+    b.T, b.hd = 200, 48
+    assert lib.wj_attn_fwd(ctypes.byref(b), None) == -3               # unsupported head dim
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = small_model()
+    audio = torch.zeros(1, 1, 32159)
+    ctx = torch.zeros(1, 200, dtype=torch.bool)
+    tg = torch.zeros(1, 4, 200, dtype=torch.bool)
+    with pytest.raises(RuntimeError):
+        m(audio, ctx, tg, tg)
+    with pytest.raises(RuntimeError):
+        m.get_audio_representation(audio, None)
+    with pytest.raises(RuntimeError):
+        m.extract_audio(audio)
+
+
+class Pinned:
+    def __init__(self, base):
+        self.base, self.k, self.orig = base, 0, np.random.default_rng
+
+    def __call__(self, seed=None):
+        g = self.orig(self.base + self.k)
+        self.k += 1
+        return g
+
+    def __enter__(self):
+        np.random.default_rng = self
+        return self
+
+    def __exit__(self, *a):
+        np.random.default_rng = self.orig
+
+
+def test_maskers_bit_exact_with_reference_fixtures(golden_dir):
+    from wavjepa_amd.masking import SpeechMasker, TimeInverseBlockMasker
+    fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    with Pinned(int(fx["as_base"])):
+        c, t, v = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)(batch_size=8, n_times=200, in_channels=1)
+    assert np.array_equal(c.numpy(), fx["as_ctx"]) and np.array_equal(t.numpy(), fx["as_tgt"]) and np.array_equal(v.numpy(), fx["as_vis"])
+    with Pinned(int(fx["ls_base"])):
+        c, t, v = SpeechMasker(4, 0.1, 10, 0.5, 5)(batch_size=8, n_times=200, in_channels=1)
+    assert np.array_equal(c.numpy(), fx["ls_ctx"]) and np.array_equal(t.numpy(), fx["ls_tgt"]) and np.array_equal(v.numpy(), fx["ls_vis"])
+    with Pinned(int(fx["as400_base"])):
+        c, t, v = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)(batch_size=4, n_times=400, in_channels=1)
+    assert np.array_equal(c.numpy(), fx["as400_ctx"]) and np.array_equal(t.numpy(), fx["as400_tgt"])
+
+
+def test_masker_statistics():
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    c, t, v = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)(batch_size=64, n_times=200, in_channels=1)
+    ctx = (~c).sum(-1).float()
+    assert c.dtype == torch.bool and t.shape == (64, 4, 200) and v.shape == (64, 4, 200)
+    assert 25 < float(ctx.mean()) < 55 and float(ctx.min()) >= 20          # survey: mean 38.7, cutoff 0.1 * 200
+    assert 38 < float(t.sum(-1).float().mean()) < 50                       # survey: 45.6 targets per group
+    assert not ((~c)[:, None] & t).any()
+
+
+def test_positions_and_schedules_match_reference(golden_dir):
+    from wavjepa_amd.jepa import cosine_schedule_with_warmup
+    from wavjepa_amd.pos_embed import get_1d_sincos_pos_embed_from_grid
+    fx = dict(np.load(os.path.join(golden_dir, "misc.npz")))
+    for d in (768, 384, 64):
+        tab = torch.from_numpy(get_1d_sincos_pos_embed_from_grid(d, np.arange(200, dtype=np.float64))).float().numpy()
+        assert np.array_equal(tab[::13, ::17], fx[f"pos{d}_slice"]) and np.array_equal(tab[199], fx[f"pos{d}_row199"])
+    m = small_model()
+    for s, d in zip(fx["ema_steps"], fx["ema_decay"]):
+        m.global_step = int(s)
+        assert abs(m._get_ema_decay() - d) < 1e-15
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = cosine_schedule_with_warmup(opt, 100000, 375000)
+    for s, l in zip(fx["lr_steps"], fx["lr_lambda"]):
+        assert abs(sch.lr_lambdas[0](int(s)) - l) < 1e-15
+    ext = m.extract_audio
+    for L, n in zip(fx["patch_lens"], fx["patch_counts"]):
+        assert ext.total_patches(int(L)) == int(n)
+    assert m.target_length == 32159 and m.total_patches == 200
+
+
+def test_state_dict_layout_matches_reference():
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.jepa import JEPA
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    ext = ConvFeatureExtractor(conv_layers_spec=SPEC, in_channels=1)
+    with torch.device("meta"):
+        pass
+    m = JEPA(feature_extractor=ext, transformer_encoder_cfg=TransformerEncoderCFG.create(), transformer_encoder_layers_cfg=TransformerLayerCFG.create(),
+             transformer_decoder_cfg=TransformerEncoderCFG.create(), transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384),
+             average_top_k_layers=8, process_audio_seconds=2.01, nr_samples_per_audio=8)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref = synth.jepa_shapes(conv_spec=SPEC, in_channels=1, d_enc=768, enc_layers=12, d_dec=384, dec_layers=12, n_tokens=200)
+    assert shapes == ref and len(shapes) == 457
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 111012864          # SURVEY measured values
+    assert sum(v.numel() for v in m.state_dict().values()) == 196299264
+    # reference init quirks: teacher == student; in_proj identical across layers, Linear weights re-drawn per layer
+    sd = m.state_dict()
+    assert torch.equal(sd["encoder.layers.3.linear1.weight"], sd["teacher_encoder.layers.3.linear1.weight"])
+    assert torch.equal(sd["encoder.layers.0.self_attn.in_proj_weight"], sd["encoder.layers.5.self_attn.in_proj_weight"])
+    assert not torch.equal(sd["encoder.layers.0.linear1.weight"], sd["encoder.layers.5.linear1.weight"])
+    assert float(sd["encoder.layers.0.linear1.weight"].abs().max()) <= 2.0 and abs(float(sd["encoder.layers.0.linear1.weight"].std()) - 0.02) < 2e-3
+    assert all(not p.requires_grad for p in m.teacher_encoder.parameters())
+
+
+def test_flat_params_and_gradient_bucket_tiling():
+    from wavjepa_amd.ddp import section_ranges
+    from wavjepa_amd.params import FlatParams
+    m = small_model()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = FlatParams(m, torch.device("cpu"))
+    assert flat.owns(m)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k                      # re-pointing to flat storage keeps every value
+    assert flat.n % 8 == 0 and all(s.offset % 8 == 0 for s in flat.slots)
+    # parameters alias the flat buffers: a write through the buffer is visible in the module and vice versa
+    flat.p32.zero_()
+    assert float(m.encoder.layers[1].linear2.weight.abs().sum()) == 0.0
+    m.mask_token.data.fill_(3.0)
+    s = flat.by_name["mask_token"]
+    assert float(flat.p32[s.offset]) == 3.0
+    ranges = section_ranges(flat, enc_layers=3, enc_chunk=2)
+    assert set(ranges) == {"dec", "enc:1", "enc:0", "front"}
+    total = sum(hi - lo for v in ranges.values() for lo, hi in v)
+    assert total == flat.n
+    # student-encoder slice mirrors the teacher buffer (single-kernel EMA)
+    assert flat.enc_numel == flat.tn
+
+
+def test_conv_geometry_and_mask_plan():
+    from wavjepa_amd.engine import conv_geometry, make_mask_plan
+    L, P = conv_geometry(32159, SPEC)
+    assert L == [6430, 3214, 1606, 802, 400, 200] and P == [6432, 3216, 1608, 804, 402, 201]
+    L2, P2 = conv_geometry(64160, SPEC)
+    assert L2[-1] == 400 and all(P2[i] == 2 * P2[i + 1] for i in range(5)) and all(p > l for p, l in zip(P2, L2))
+    w2v = SPEC + [(512, 2, 2)]
+    L3, P3 = conv_geometry(64320, w2v)
+    assert L3[-1] == 200 and all(P3[i] == 2 * P3[i + 1] for i in range(6))
+    ctx = torch.tensor([[True, False, False, True], [False, True, True, False]])
+    tgt = torch.zeros(2, 2, 4, dtype=torch.bool)
+    plan = make_mask_plan(ctx, tgt, tgt, torch.device("cpu"))
+    assert plan.n_ctx == 4 and plan.keep.tolist() == [1, 2, 4, 7] and plan.inv.tolist() == [-1, 0, 1, -1, 2, -1, -1, 3]
+    assert plan.vis_u8.shape == (4, 4)
+
+
+def test_config_loader_and_factories():
+    import train
+    from wavjepa_amd.config import load_config, parse_conv_spec
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
+    cfg = load_config(root, ["masker=LibriSpeech", "trainer.steps=100", "optimizer.lr=1e-3", "extractor=wav2vec2"])
+    assert cfg.masker.name == "speech-masker" and cfg.trainer.steps == 100 and cfg.optimizer.lr == 1e-3
+    assert len(parse_conv_spec(cfg.extractor.conv_layers_spec)) == 7
+    with pytest.raises(ValueError):
+        parse_conv_spec("__import__('os').system('true')")
+    cfg = load_config(root)
+    mk = train.ComponentFactory.create_masker(cfg)                 # YAML spelling context_mask_prob is accepted
+    assert mk.context_mask_prob == 0.65 and mk.context_mask_length == 10
+    cfg.masker["context_prob"] = 0.5                               # ... and so is the spelling train.py reads upstream
+    assert train.ComponentFactory.create_masker(cfg).context_mask_prob == 0.5
+    cfg.extractor["name"] = "nope"
+    with pytest.raises(ValueError):
+        train.ComponentFactory.create_extractor(cfg)
+    model, patches = train.build_model(load_config(root))
+    assert patches == 200 and model.hparams.lr == 0.0004 and model.hparams.adam_weight_decay == 0.04
+
+
+def test_hear_runtime_padding_arithmetic():
+    from hear_api.runtime import calculate_padding_mask, get_timestamps, strip_compile_prefixes
+
+    class M:
+        device = torch.device("cpu")
+
+    for n in (16000, 32159, 50000, 160000):
+        unit = 32159
+        pad = unit - (n % unit)
+        total = n + pad
+        mask, cut = calculate_padding_mask(pad, total, 16000, 200, 32159 // 16000, M(), 2)
+        assert mask.shape[0] == 2 and mask.shape[1] == 200 * (total // unit)
+        assert int(mask[0].sum()) == mask.shape[1] - cut and (cut == mask.shape[1] or bool(mask[0, cut]))
+    ts = get_timestamps(16000, 2, 32000, torch.zeros(2, 100, 8))
+    assert ts.shape == (2, 100) and abs(float(ts[0, 1]) - 20.0) < 1e-6
+    sd = strip_compile_prefixes({"encoder._orig_mod.layers.0.linear1.weight": 1, "mask_token": 2})
+    assert set(sd) == {"encoder.layers.0.linear1.weight", "mask_token"}
