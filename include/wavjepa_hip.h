@@ -34,7 +34,7 @@ int wj_struct_size(const char* name);
  * channels-last activation (extractors/audio_feature_extractor.py:66-70).
  *   C[M,N] = opA(A) . opB(B);  a_trans=0: A is [M][K] (K contiguous);  a_trans=1: A is stored [K][M] (M contiguous)
  *                              b_trans=0: B is [N][K] (K contiguous);  b_trans=1: B is stored [K][N] (N contiguous)
- * Requirements: N%8==0, lda%8==0, ldb%8==0, ldc%4==0; a_trans also needs M%8==0; K%8==0 unless both operands are
+ * Requirements: N%8==0, lda%8==0, ldb%8==0, ldc%8==0, A/B/C 16-byte aligned; a_trans also needs M%8==0; K%8==0 unless both operands are
  * col form (wgrad: K = token rows, arbitrary).
  * -----------------------------------------------------------------------------------------------------------*/
 enum {

@@ -1,174 +1,152 @@
-// bf16 MFMA GEMM for gfx950 with fused epilogues: the dense-contraction engine of the WavJEPA step
+// bf16 MFMA GEMM for gfx950, generation 2: the dense-contraction engine of the WavJEPA step
 // (QKV / out-proj / MLP / mappers / predictor, their dgrad + wgrad, and conv layers 1..5 as implicit GEMM
 // over a channels-last activation with overlapping rows: lda = stride*C, K = k*C).
 //
 //   C[M,N] = opA(A) . opB(B)      fp32 accumulate on v_mfma_f32_16x16x32_bf16
-//     a_trans = 0 : A stored [M][K], K contiguous, row stride lda          ("row form")
-//     a_trans = 1 : A stored [K][M], M contiguous, row stride lda          ("col form", read with ds_read_b64_tr_b16)
-//     b_trans = 0 : B stored [N][K], K contiguous (nn.Linear weight)       ("row form")
-//     b_trans = 1 : B stored [K][N], N contiguous                          ("col form")
-//   forward  y = x W^T      : (0,0)      dgrad dx = dy W : (0,1)      wgrad dW = dy^T x : (1,1)
+//     a_trans = 0 : A stored [M][K], K contiguous ("row form")      a_trans = 1 : A stored [K][M], M contiguous ("col form")
+//     b_trans = 0 : B stored [N][K], K contiguous (nn.Linear)       b_trans = 1 : B stored [K][N], N contiguous
+//   forward  y = x W^T : (0,0)      dgrad dx = dy W : (0,1)      wgrad dW = dy^T x : (1,1)
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), wave tile 64x64 = 4x4 MFMA tiles.  Operands are staged
-// global -> VGPR (16 B/lane) -> LDS with the loads of tile t+1 issued before the MFMAs of tile t and the LDS
-// write after them (one barrier per K tile, two LDS stages).  Row-form tiles are XOR-swizzled on 16-B chunks
-// (conflict-free ds_read_b128), col-form tiles are padded to 288-B rows (conflict-free tr reads).
-// The MFMA is issued with the operands swapped (B fragment first) so that every lane ends up owning 4
-// consecutive N-columns of one output row: 8-B (bf16) / 16-B (fp32) epilogue stores and float4 bias loads.
-// Workgroup ids are remapped so that the N-tiles sharing an A panel run on one XCD (shared L2).
+// Structure (one workgroup of 8 waves per CU, 2 waves per SIMD):
+//   * 256 x 128 x 64 tile, waves 4(M) x 2(N), 64x64 per wave = 4x4 MFMA tiles.
+//   * Operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR staging)
+//     into a 3-stage ring; tile t+2 is issued while tile t is computed, and the only wait in the loop is a COUNTED
+//     s_waitcnt vmcnt(6) (this wave's 6 loads of tile t+1 stay in flight) + one raw s_barrier per K tile.
+//   * The LDS image is lane-linear (what LDS-DMA can write); bank-conflict-free reads come from an XOR swizzle
+//     applied to the per-lane SOURCE address and again on the read: 16-B chunk ^ (row & 7) for row-form tiles
+//     (ds_read_b128), 32-B column ^ f(k) for col-form tiles (ds_read_b64_tr_b16 transposed reads).
+//   * K tails / out-of-range columns read a 256-B zero page instead of being predicated; out-of-range rows are
+//     clamped (their outputs are never stored).
+//   * MFMA operands are swapped (B fragment first) so a lane owns 4 consecutive output columns; the accumulators
+//     are staged through LDS (which is free again after the loop) and written as whole rows: 16-B coalesced
+//     stores, row-contiguous 256-B float atomics for the split-K wgrad.
+//   * Workgroup ids are remapped so that the N-tiles sharing an A panel run on one XCD (shared L2).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
 
+extern "C" int wj_gemm_bf16_v1(const wj_gemm_args* a, void* stream);
+
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int ROW_TILE_BYTES = 128 * 128;          // [128 rows][64 k] bf16, 128-B rows
-constexpr int COL_ROW_BYTES = 288;                 // [64 k][128 rows] bf16, 256-B rows padded by 32 B
-constexpr int COL_TILE_BYTES = 64 * COL_ROW_BYTES;  // 18432
-constexpr int OPER_BYTES = COL_TILE_BYTES;         // per operand per stage (max of the two forms)
-constexpr int STAGE_BYTES = 2 * OPER_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;          // 73728
+constexpr int BM = 256, BN = 128, BK = 64, NT = 512, STAGES = 3;
+constexpr int A_BYTES = BM * BK * 2;             // 32768
+constexpr int B_BYTES = BN * BK * 2;             // 16384
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 49152
+constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // 147456
+constexpr int LOADS_PER_TILE = STAGE_BYTES / 1024 / 8;  // LDS-DMA instructions per wave per K tile = 6
+constexpr int CP_BF16 = BN * 2 + 16;             // C staging pitch (bytes), bf16 tile: 272
+constexpr int CP_F32 = BN * 4 + 16;              // fp32 tile: 528  (256 * 528 = 135168 <= LDS_BYTES)
 
-struct Chunk4 { uint4 v[4]; };
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
-// ---- global -> registers -------------------------------------------------------------------------------
-// Row form: tile rows r0..r0+127 (limit R), k range k0..k0+63 (limit kend).  Thread t: chunk c = t&7, rows (t>>3)+32i.
-template <bool TRANS>
-__device__ __forceinline__ void load_tile(Chunk4& out, const bf16_t* __restrict__ base, long ld, int r0, int R,
-                                          int k0, int kend, int t) {
-    if constexpr (!TRANS) {
-        const int c = t & 7, rr = t >> 3;
-        const int k = k0 + c * 8;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gl_void;
+
+// Branch-free pointer select (a ?: on pointers becomes EXEC-masked duplicate LDS-DMA instructions).
+__device__ __forceinline__ const bf16_t* sel_ptr(bool ok, const bf16_t* p, const bf16_t* z) {
+    const unsigned long long m = 0ull - (unsigned long long)ok;
+    return reinterpret_cast<const bf16_t*>((reinterpret_cast<unsigned long long>(p) & m) |
+                                           (reinterpret_cast<unsigned long long>(z) & ~m));
+}
+
+// ---- HBM -> LDS: this wave's share of one operand tile ------------------------------------------------------
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restrict__ base, long ld, int r0, int R, int k0,
+                                           int kend, int wave, int lane, const bf16_t* zero) {
+    constexpr int PER_WAVE = ROWS * 128 / 1024 / 8;  // wave-instructions of 1 KiB: 4 (A) or 2 (B)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = r0 + rr + 32 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < R && k < kend) v = *reinterpret_cast<const uint4*>(base + (long)row * ld + k);
-            out.v[i] = v;
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int j = wave * PER_WAVE + u;
+        const bf16_t* src;
+        if constexpr (!TRANS) {
+            // [ROWS][64 k] image, 128-B rows: LDS position (row, chunk p) holds source chunk p ^ (row & 7)
+            const int row = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            int grow = r0 + row;
+            grow = grow < R ? grow : R - 1;
+            const int k = k0 + c * 8;
+            src = sel_ptr(k < kend, base + (long)grow * ld + k, zero);
+        } else {
+            // [64 k][ROWS] image: LDS position (k row, chunk p) holds source chunk p ^ (f(k) << 1),
+            // f(k) = (k & 3) | ((k >> 3) & 1) << 2  -> the 8 k-rows one transposed read touches hit 8 distinct 32-B columns
+            constexpr int CPR = ROWS / 8;   // 16-B chunks per k row
+            constexpr int RPI = 64 / CPR;   // k rows per wave-instruction
+            const int krow = j * RPI + lane / CPR;
+            const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+            const int c = (lane % CPR) ^ (f << 1);
+            const int k = k0 + krow;
+            const int row = r0 + c * 8;
+            src = sel_ptr(k < kend && row < R, base + (long)k * ld + row, zero);
         }
-    } else {
-        // Col form: memory rows are k, 128 tile-rows contiguous (16 chunks of 8).  Thread t: chunk c = t&15, k rows (t>>4)+16i.
-        const int c = t & 15, kk = t >> 4;
-        const int row = r0 + c * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + kk + 16 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (k < kend && row < R) v = *reinterpret_cast<const uint4*>(base + (long)k * ld + row);
-            out.v[i] = v;
-        }
+        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(lds_tile + j * 1024), 16, 0, 0);
     }
 }
 
-// ---- registers -> LDS ----------------------------------------------------------------------------------
-template <bool TRANS>
-__device__ __forceinline__ void store_tile(char* lds, const Chunk4& in, int t) {
-    if constexpr (!TRANS) {
-        const int c = t & 7, rr = t >> 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = rr + 32 * i;
-            *reinterpret_cast<uint4*>(lds + row * 128 + ((c ^ (row & 7)) << 4)) = in.v[i];
-        }
-    } else {
-        const int c = t & 15, kk = t >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = kk + 16 * i;
-            // rows k and k+8 would share banks (8 banks/row shift, period 8): flip the 128-B half for odd k/8
-            *reinterpret_cast<uint4*>(lds + k * COL_ROW_BYTES + ((c ^ (((k >> 3) & 1) << 3)) << 4)) = in.v[i];
-        }
-    }
-}
-
-// ---- LDS -> MFMA fragment: lane (i = lane&15, g = lane>>4) gets tile-row (rbase+i), k = ks*32 + 8g + 0..7 ----
-template <bool TRANS>
-__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int ks, int lane) {
+// ---- LDS -> 4 MFMA fragments (tile rows rbase0 + 16x + i, k = ks*32 + 8g + 0..7; i = lane&15, g = lane>>4) -----
+// Row form: plain ds_read_b128 (the compiler counts them with lgkmcnt).
+// Col form: ds_read_b64_tr_b16 transposed reads issued from ONE inline-asm statement together with their
+// lgkmcnt(0): through the intrinsic, hipcc cannot prove the read does not alias the LDS-DMA still in flight and
+// emits s_waitcnt vmcnt(0) before it every K tile, which would drain the 3-stage prefetch ring.
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void load_frags(bf16x8 (&f)[4], const char* tile, int rbase0, int ks, int lane) {
     const int i = lane & 15, g = lane >> 4;
     if constexpr (!TRANS) {
-        const int row = rbase + i;
         const int c = ks * 4 + g;
-        return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ (row & 7)) << 4));
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int row = rbase0 + x * 16 + i;
+            f[x] = *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ (row & 7)) << 4));
+        }
     } else {
-        // two transposed 4x16 block reads: lane 4q+p of each 16-lane group addresses (k row q, columns 4p..4p+3)
         const int q = i >> 2, p = i & 3;
         const int k = ks * 32 + 8 * g + q;
-        const char* a0 = lds + k * COL_ROW_BYTES + (((rbase + 4 * p) << 1) ^ ((g & 1) << 7));
-        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a0 + 4 * COL_ROW_BYTES));
-        bf16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
+        const int fx = (q | ((g & 1) << 2)) << 5;   // f(k) == f(k + 4), as a byte XOR on the 32-B column
+        const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)tile + k * (ROWS * 2);
+        const unsigned a0 = base + ((((rbase0 + 0) + 4 * p) << 1) ^ fx);
+        const unsigned a1 = base + ((((rbase0 + 16) + 4 * p) << 1) ^ fx);
+        const unsigned a2 = base + ((((rbase0 + 32) + 4 * p) << 1) ^ fx);
+        const unsigned a3 = base + ((((rbase0 + 48) + 4 * p) << 1) ^ fx);
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\t"
+            "ds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\t"
+            "ds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+            "ds_read_b64_tr_b16 %4, %10\n\t"
+            "ds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+            "ds_read_b64_tr_b16 %6, %11\n\t"
+            "ds_read_b64_tr_b16 %7, %11 offset:%12\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(4 * ROWS * 2)
+            : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
 struct EpiArgs {
-    void* C;            // primary output
-    void* C2;           // secondary output (EPI_BIAS_GELU2 / EPI_CONV_GELU: post-activation)
-    const float* bias;  // [N] or null
-    const void* aux;    // EPI_MUL_GELU_GRAD: pre-activation h (bf16, ldc); EPI_ADD_F32: addend (fp32, ldc)
+    void* C;
+    void* C2;
+    const float* bias;
+    const void* aux;
     long ldc;
-    int seg_rows;       // EPI_CONV_GELU: rows per clip segment (P) and valid rows (L): rows (m % P) >= L are written as 0
-    int seg_valid;
+    int seg_rows, seg_valid;
     float alpha;
 };
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, f32x4 acc, int N) {
-    // acc[r] belongs to C[m][n + r], r = 0..3 (n is a multiple of 4, N % 4 == 0)
-    if (n >= N) return;
-    const long off = (long)m * e.ldc + n;
-    if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
-        if (e.bias) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
-            acc += b;
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[r]);
-        *reinterpret_cast<bf16x4*>((bf16_t*)e.C + off) = o;
-        if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
-            bf16x4 g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = f2bf(gelu_f(bf2f(o[r])));
-            *reinterpret_cast<bf16x4*>((bf16_t*)e.C2 + off) = g;
-        }
-    } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>((const bf16_t*)e.aux + off);
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(f2bf(acc[r])) * gelu_grad_f(bf2f(h[r])));
-        *reinterpret_cast<bf16x4*>((bf16_t*)e.C + off) = o;
-    } else if constexpr (EPI == WJ_EPI_ADD_F32) {
-        f32x4 o = acc;
-        if (e.aux) o += *reinterpret_cast<const f32x4*>((const float*)e.aux + off);
-        *reinterpret_cast<f32x4*>((float*)e.C + off) = o;
-    } else if constexpr (EPI == WJ_EPI_ATOMIC_F32) {
-        float* c = (float*)e.C + off;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(c + r, acc[r] * e.alpha);
-    } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
-        const bool valid = (m % e.seg_rows) < e.seg_valid;
-        bf16x4 pre, post;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pre[r] = valid ? f2bf(acc[r]) : f2bf(0.f);
-            post[r] = valid ? f2bf(gelu_f(bf2f(pre[r]))) : f2bf(0.f);
-        }
-        *reinterpret_cast<bf16x4*>((bf16_t*)e.C + off) = pre;
-        *reinterpret_cast<bf16x4*>((bf16_t*)e.C2 + off) = post;
-    }
-}
-
-template <bool ATRANS, bool BTRANS, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                     long lda, long ldb, int M, int N, int K, int tiles_n,
-                                                     int split_k, int k_per_split, EpiArgs epi) {
+template <bool AT, bool BT, int EPI>
+__global__ __launch_bounds__(NT, 1) void gemm2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, long lda,
+                                                      long ldb, int M, int N, int K, int tiles_n, int split_k,
+                                                      int k_per_split, EpiArgs e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = wg / split_k, ksl = wg - tile * split_k;
@@ -177,6 +155,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const bf16_t* __restrict__ 
     const int kbeg = ksl * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
     const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (EPI == WJ_EPI_ATOMIC_F32 && nkt <= 0) return;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -185,55 +164,146 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const bf16_t* __restrict__ 
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nkt > 0) {
-        Chunk4 ra, rb;
-        load_tile<ATRANS>(ra, A, lda, m0, M, kbeg, kend, t);
-        load_tile<BTRANS>(rb, B, ldb, n0, N, kbeg, kend, t);
-        store_tile<ATRANS>(smem, ra, t);
-        store_tile<BTRANS>(smem + OPER_BYTES, rb, t);
-        __syncthreads();
-
+        stage_tile<AT, BM>(smem, A, lda, m0, M, kbeg, kend, wave, lane, zero);
+        stage_tile<BT, BN>(smem + A_BYTES, B, ldb, n0, N, kbeg, kend, wave, lane, zero);
+        if (nkt > 1) {
+            stage_tile<AT, BM>(smem + STAGE_BYTES, A, lda, m0, M, kbeg + BK, kend, wave, lane, zero);
+            stage_tile<BT, BN>(smem + STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + BK, kend, wave, lane, zero);
+        }
+        int cur = 0;                      // stage holding tile kt
         for (int kt = 0; kt < nkt; ++kt) {
-            char* cur = smem + (kt & 1) * STAGE_BYTES;
-            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            const bool more = (kt + 1) < nkt;
-            if (more) {
-                const int k0 = kbeg + (kt + 1) * BK;
-                load_tile<ATRANS>(ra, A, lda, m0, M, k0, kend, t);
-                load_tile<BTRANS>(rb, B, ldb, n0, N, k0, kend, t);
+            // tile kt has landed once all but this wave's newest LOADS_PER_TILE LDS-DMA ops are done; the barrier makes
+            // every wave's share visible and proves every wave is past its reads of stage (kt+2) % 3 (= tile kt-1).
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nkt) {
+                const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
+                char* st = smem + nxt * STAGE_BYTES;
+                const int k0 = kbeg + (kt + 2) * BK;
+                stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
+                stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
             }
+            const char* sa = smem + cur * STAGE_BYTES;
+            const char* sb = sa + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 af[4], bfr[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) af[x] = read_frag<ATRANS>(cur, wm * 64 + x * 16, ks, lane);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) bfr[x] = read_frag<BTRANS>(cur + OPER_BYTES, wn * 64 + x * 16, ks, lane);
+                load_frags<AT, BM>(af, sa, wm * 64, ks, lane);
+                load_frags<BT, BN>(bfr, sb, wn * 64, ks, lane);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
             }
-            if (more) {
-                store_tile<ATRANS>(nxt, ra, t);
-                store_tile<BTRANS>(nxt + OPER_BYTES, rb, t);
-            }
-            __syncthreads();
+            cur = cur == 2 ? 0 : cur + 1;
         }
-    } else if (EPI == WJ_EPI_ATOMIC_F32) {
-        return;  // empty K slice contributes nothing
     }
 
-    // epilogue: lane (i, g) owns C[m0 + wm*64 + mi*16 + i][n0 + wn*64 + ni*16 + 4g .. +3]
+    // ---- epilogue: accumulators -> LDS tile -> whole rows -------------------------------------------------
+    __syncthreads();
     const int i = lane & 15, g = lane >> 4;
+    constexpr bool F32_TILE = (EPI == WJ_EPI_ADD_F32 || EPI == WJ_EPI_ATOMIC_F32);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + i;
-        if (m >= M) continue;
+        const int m = wm * 64 + mi * 16 + i;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
-            epilogue_store<EPI>(epi, m, n, acc[mi][ni], N);
+            const int n = wn * 64 + ni * 16 + 4 * g;
+            f32x4 v = acc[mi][ni];
+            if constexpr (F32_TILE) {
+                *reinterpret_cast<f32x4*>(smem + m * CP_F32 + n * 4) = v;
+            } else {
+                if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
+                    if (e.bias && n0 + n < N) v += *reinterpret_cast<const f32x4*>(e.bias + n0 + n);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                *reinterpret_cast<bf16x4*>(smem + m * CP_BF16 + n * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    if constexpr (EPI == WJ_EPI_ATOMIC_F32) {
+        // one float per lane, a wave covers half a row: 256 contiguous bytes per atomic wave-instruction
+        const int col = t & 127, rr = t >> 7;
+        const int n = n0 + col;
+        if (n < N) {
+#pragma unroll 8
+            for (int r = rr; r < BM; r += 4) {
+                const int m = m0 + r;
+                if (m < M) {
+                    const float v = *reinterpret_cast<const float*>(smem + r * CP_F32 + col * 4);
+                    atomicAdd((float*)e.C + (long)m * e.ldc + n, v * e.alpha);
+                }
+            }
+        }
+    } else if constexpr (EPI == WJ_EPI_ADD_F32) {
+        const int c4 = (t & 31) * 4, rr = t >> 5;   // 32 float4 chunks per row, 16 rows per pass, 16 passes
+        const int n = n0 + c4;
+        const bool ncol = n < N;
+        f32x4 ax[16];
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {           // all addend loads in flight before the first use
+            const int m = m0 + rr + 16 * ps;
+            ax[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e.aux && ncol && m < M) ax[ps] = *reinterpret_cast<const f32x4*>((const float*)e.aux + (long)m * e.ldc + n);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int r = rr + 16 * ps, m = m0 + r;
+            if (ncol && m < M) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP_F32 + c4 * 4) + ax[ps];
+                *reinterpret_cast<f32x4*>((float*)e.C + (long)m * e.ldc + n) = v;
+            }
+        }
+    } else {
+        const int c8 = (t & 15) * 8, rr = t >> 4;   // 16 chunks of 8 bf16 per row, 32 rows per pass, 8 passes
+        const int n = n0 + c8;
+        const bool ncol = n < N;
+        bf16x8 hx[8];
+        if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int m = m0 + rr + 32 * ps;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) hx[ps][x] = f2bf(0.f);
+                if (ncol && m < M) hx[ps] = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.aux + (long)m * e.ldc + n);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int r = rr + 32 * ps, m = m0 + r;
+            if (!(ncol && m < M)) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CP_BF16 + c8 * 2);
+            const long off = (long)m * e.ldc + n;
+            if constexpr (EPI == WJ_EPI_BF16) {
+                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
+            } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
+                bf16x8 gl;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
+                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
+                *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
+            } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
+                bf16x8 o;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * gelu_grad_f(bf2f(hx[ps][x])));
+                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
+            } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
+                const bool valid = (m % e.seg_rows) < e.seg_valid;
+                bf16x8 pre, post;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    pre[x] = valid ? v[x] : f2bf(0.f);
+                    post[x] = valid ? f2bf(gelu_f(bf2f(v[x]))) : f2bf(0.f);
+                }
+                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = pre;
+                *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = post;
+            }
         }
     }
 }
@@ -248,12 +318,9 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     e.C = a->C; e.C2 = a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
-    static bool attr_set = false;
-    auto kern = gemm_kernel<AT, BT, EPI>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    auto kern = gemm2_kernel<AT, BT, EPI>;
+    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return WJ_ERR_LAUNCH;
     const int nwg = tiles_m * tiles_n * split;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), LDS_BYTES, s, (const bf16_t*)a->A, (const bf16_t*)a->B, (long)a->lda,
                        (long)a->ldb, a->M, a->N, a->K, tiles_n, split, kps, e);
@@ -279,12 +346,15 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
 extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return WJ_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return WJ_ERR_ARG;
-    if ((a->N & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 3)) return WJ_ERR_ARG;
+    if ((a->N & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 7)) return WJ_ERR_ARG;
     if ((!a->a_trans || !a->b_trans) && (a->K & 7)) return WJ_ERR_ARG;  // row-form operands are read in 8-element K chunks
     if (a->a_trans && (a->M & 7)) return WJ_ERR_ARG;
+    if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return WJ_ERR_ARG;
     if ((a->epilogue == WJ_EPI_BIAS_GELU2 || a->epilogue == WJ_EPI_CONV_GELU) && !a->C2) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD && !a->aux) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
+    static const bool use_v1 = getenv("WJ_GEMM_V1") != nullptr;
+    if (use_v1) return wj_gemm_bf16_v1(a, stream);
     hipStream_t s = (hipStream_t)stream;
     if (!a->a_trans && !a->b_trans) return dispatch_epi<false, false>(a, s);
     if (!a->a_trans && a->b_trans) return dispatch_epi<false, true>(a, s);

@@ -71,9 +71,9 @@ def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, 
 
 
 def pick_split_k(M: int, N: int, K: int, target_wgs: int = 512) -> int:
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles = ((M + 255) // 256) * ((N + 127) // 128)        # the GEMM tile is 256 x 128
     s = max(1, target_wgs // max(1, tiles))
-    return max(1, min(s, (K + 511) // 512))
+    return max(1, min(s, (K + 1023) // 1024))
 
 
 # ---------------------------------------------------------------------------------------------------------- norms
