@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM for gfx950, generation 2: the dense-contraction engine of the WavJEPA step
+// bf16 MFMA GEMM for gfx950, generation 3: the dense-contraction engine of the WavJEPA step
 // (QKV / out-proj / MLP / mappers / predictor, their dgrad + wgrad, and conv layers 1..5 as implicit GEMM
 // over a channels-last activation with overlapping rows: lda = stride*C, K = k*C).
 //
@@ -7,19 +7,25 @@
 //     b_trans = 0 : B stored [N][K], K contiguous (nn.Linear)       b_trans = 1 : B stored [K][N], N contiguous
 //   forward  y = x W^T : (0,0)      dgrad dx = dy W : (0,1)      wgrad dW = dy^T x : (1,1)
 //
-// Structure (one workgroup of 8 waves per CU, 2 waves per SIMD):
-//   * 256 x 128 x 64 tile, waves 4(M) x 2(N), 64x64 per wave = 4x4 MFMA tiles.
-//   * Operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR staging)
-//     into a 3-stage ring; tile t+2 is issued while tile t is computed, and the only wait in the loop is a COUNTED
-//     s_waitcnt vmcnt(6) (this wave's 6 loads of tile t+1 stay in flight) + one raw s_barrier per K tile.
+// Measured on MI355X (PMC): with a 256x128 tile the loop is bound by operand delivery L2 -> LDS (MFMA pipe 40 %
+// busy, LDS 21 %), so the tile is as wide as N allows:
+//   * BN = 256: 256 x 256 x 32 tile (128 FLOP per operand byte), 8 waves 2(M) x 4(N), 128x64 per wave (8x4 MFMA
+//     tiles, 128 accumulator VGPRs), 4-stage LDS ring (128 KiB), one workgroup per CU.
+//   * BN = 128: 256 x 128 x 32 tile, 8 waves 4(M) x 2(N), 64x64 per wave, 3-stage ring (72 KiB), TWO workgroups per CU
+//     (one's prologue / VALU-heavy epilogue overlaps the other's MFMA loop) - used when N is not a multiple of 256.
+// Common structure:
+//   * Operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR staging);
+//     tile t+STAGES-1 is issued while tile t is computed; the only VMEM wait in the loop is a COUNTED s_waitcnt
+//     vmcnt(n) that leaves the younger tiles in flight, followed by one raw s_barrier per K tile.
 //   * The LDS image is lane-linear (what LDS-DMA can write); bank-conflict-free reads come from an XOR swizzle
-//     applied to the per-lane SOURCE address and again on the read: 16-B chunk ^ (row & 7) for row-form tiles
-//     (ds_read_b128), 32-B column ^ f(k) for col-form tiles (ds_read_b64_tr_b16 transposed reads).
+//     applied to the per-lane SOURCE address and again on the read (row-form 64-B rows: 16-B chunk ^ h[(row>>2)&3];
+//     col-form: 32-B column ^ f(k)).  Col-form fragments are read with ds_read_b64_tr_b16 from inline asm (through
+//     the intrinsic hipcc inserts vmcnt(0) before every read, draining the ring).
 //   * K tails / out-of-range columns read a 256-B zero page instead of being predicated; out-of-range rows are
 //     clamped (their outputs are never stored).
 //   * MFMA operands are swapped (B fragment first) so a lane owns 4 consecutive output columns; the accumulators
-//     are staged through LDS (which is free again after the loop) and written as whole rows: 16-B coalesced
-//     stores, row-contiguous 256-B float atomics for the split-K wgrad.
+//     are staged through LDS in row chunks and written as whole rows: 16-B coalesced stores, row-contiguous
+//     256-B float atomics for the split-K wgrad.
 //   * Workgroup ids are remapped so that the N-tiles sharing an A panel run on one XCD (shared L2).
 #include <stdlib.h>
 #include "common.h"
@@ -29,14 +35,23 @@ extern "C" int wj_gemm_bf16_v1(const wj_gemm_args* a, void* stream);
 
 namespace {
 
-constexpr int BM = 256, BN = 128, BK = 64, NT = 512, STAGES = 3;
-constexpr int A_BYTES = BM * BK * 2;             // 32768
-constexpr int B_BYTES = BN * BK * 2;             // 16384
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 49152
-constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // 147456
-constexpr int LOADS_PER_TILE = STAGE_BYTES / 1024 / 8;  // LDS-DMA instructions per wave per K tile = 6
-constexpr int CP_BF16 = BN * 2 + 16;             // C staging pitch (bytes), bf16 tile: 272
-constexpr int CP_F32 = BN * 4 + 16;              // fp32 tile: 528  (256 * 528 = 135168 <= LDS_BYTES)
+constexpr int BM = 256, BK = 32, NT = 512;
+
+template <int BN> struct Cfg {
+    static constexpr int STAGES = BN == 256 ? 4 : 3;
+    static constexpr int A_BYTES = BM * BK * 2;                        // 16384
+    static constexpr int B_BYTES = BN * BK * 2;                        // 16384 / 8192
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;              // 32768 / 24576
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;             // 131072 / 73728
+    static constexpr int LOADS_PER_TILE = STAGE_BYTES / 1024 / 8;      // LDS-DMA instructions per wave per K tile: 4 / 3
+    static constexpr int WAVES_N = BN / 64;                            // 4 / 2
+    static constexpr int WAVES_M = 8 / WAVES_N;                        // 2 / 4
+    static constexpr int MI = BM / WAVES_M / 16;                       // m-fragments per wave: 8 / 4
+    static constexpr int CP_BF16 = BN * 2 + 16;                        // C staging pitch, bf16
+    static constexpr int CP_F32 = BN * 4 + 16;                         // fp32
+    static constexpr int RC_BF16 = BN == 256 ? 128 : 256;              // rows staged per chunk (fits LDS_BYTES)
+    static constexpr int RC_F32 = BN == 256 ? 64 : 128;
+};
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -50,25 +65,27 @@ __device__ __forceinline__ const bf16_t* sel_ptr(bool ok, const bf16_t* p, const
                                            (reinterpret_cast<unsigned long long>(z) & ~m));
 }
 
-// ---- HBM -> LDS: this wave's share of one operand tile ------------------------------------------------------
+__device__ __forceinline__ int row_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }  // h = {0,2,3,1}
+
+// ---- HBM -> LDS: this wave's share of one operand tile (ROWS x 32 k) ----------------------------------------
 template <bool TRANS, int ROWS>
 __device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restrict__ base, long ld, int r0, int R, int k0,
                                            int kend, int wave, int lane, const bf16_t* zero) {
-    constexpr int PER_WAVE = ROWS * 128 / 1024 / 8;  // wave-instructions of 1 KiB: 4 (A) or 2 (B)
+    constexpr int PER_WAVE = ROWS * BK * 2 / 1024 / 8;  // 1-KiB wave-instructions per wave: 2 (256 rows) / 1 (128 rows)
 #pragma unroll
     for (int u = 0; u < PER_WAVE; ++u) {
         const int j = wave * PER_WAVE + u;
         const bf16_t* src;
         if constexpr (!TRANS) {
-            // [ROWS][64 k] image, 128-B rows: LDS position (row, chunk p) holds source chunk p ^ (row & 7)
-            const int row = j * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (row & 7);
+            // [ROWS][32 k] image, 64-B rows: LDS position (row, chunk p) holds source chunk p ^ h[(row >> 2) & 3]
+            const int row = j * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ row_swz(row);
             int grow = r0 + row;
             grow = grow < R ? grow : R - 1;
             const int k = k0 + c * 8;
             src = sel_ptr(k < kend, base + (long)grow * ld + k, zero);
         } else {
-            // [64 k][ROWS] image: LDS position (k row, chunk p) holds source chunk p ^ (f(k) << 1),
+            // [32 k][ROWS] image: LDS position (k row, chunk p) holds source chunk p ^ (f(k) << 1),
             // f(k) = (k & 3) | ((k >> 3) & 1) << 2  -> the 8 k-rows one transposed read touches hit 8 distinct 32-B columns
             constexpr int CPR = ROWS / 8;   // 16-B chunks per k row
             constexpr int RPI = 64 / CPR;   // k rows per wave-instruction
@@ -83,24 +100,19 @@ __device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restr
     }
 }
 
-// ---- LDS -> 4 MFMA fragments (tile rows rbase0 + 16x + i, k = ks*32 + 8g + 0..7; i = lane&15, g = lane>>4) -----
-// Row form: plain ds_read_b128 (the compiler counts them with lgkmcnt).
-// Col form: ds_read_b64_tr_b16 transposed reads issued from ONE inline-asm statement together with their
-// lgkmcnt(0): through the intrinsic, hipcc cannot prove the read does not alias the LDS-DMA still in flight and
-// emits s_waitcnt vmcnt(0) before it every K tile, which would drain the 3-stage prefetch ring.
+// ---- LDS -> 4 MFMA fragments (tile rows rbase0 + 16x + i, k = 8g + 0..7; i = lane&15, g = lane>>4) ---------------
 template <bool TRANS, int ROWS>
-__device__ __forceinline__ void load_frags(bf16x8 (&f)[4], const char* tile, int rbase0, int ks, int lane) {
+__device__ __forceinline__ void load_frags4(bf16x8* f, const char* tile, int rbase0, int lane) {
     const int i = lane & 15, g = lane >> 4;
     if constexpr (!TRANS) {
-        const int c = ks * 4 + g;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int row = rbase0 + x * 16 + i;
-            f[x] = *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ (row & 7)) << 4));
+            f[x] = *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((g ^ row_swz(row)) << 4));
         }
     } else {
         const int q = i >> 2, p = i & 3;
-        const int k = ks * 32 + 8 * g + q;
+        const int k = 8 * g + q;
         const int fx = (q | ((g & 1) << 2)) << 5;   // f(k) == f(k + 4), as a byte XOR on the 32-B column
         const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)tile + k * (ROWS * 2);
         const unsigned a0 = base + ((((rbase0 + 0) + 4 * p) << 1) ^ fx);
@@ -138,14 +150,21 @@ struct EpiArgs {
     float alpha;
 };
 
-template <bool AT, bool BT, int EPI>
-__global__ __launch_bounds__(NT, 1) void gemm2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, long lda,
-                                                      long ldb, int M, int N, int K, int tiles_n, int split_k,
-                                                      int k_per_split, EpiArgs e) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool AT, bool BT, int EPI, int BN>
+__global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                      long lda, long ldb, int M, int N, int K, int tiles_n,
+                                                                      int split_k, int k_per_split, EpiArgs e) {
+    using C_ = Cfg<BN>;
+    constexpr int S = C_::STAGES, A_BYTES = C_::A_BYTES, STAGE_BYTES = C_::STAGE_BYTES, LPT = C_::LOADS_PER_TILE, MI = C_::MI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C_::WAVES_N, wn = wave % C_::WAVES_N;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -157,186 +176,224 @@ __global__ __launch_bounds__(NT, 1) void gemm2_kernel(const bf16_t* __restrict__
     const int nkt = (kend - kbeg + BK - 1) / BK;
     if (EPI == WJ_EPI_ATOMIC_F32 && nkt <= 0) return;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nkt > 0) {
-        stage_tile<AT, BM>(smem, A, lda, m0, M, kbeg, kend, wave, lane, zero);
-        stage_tile<BT, BN>(smem + A_BYTES, B, ldb, n0, N, kbeg, kend, wave, lane, zero);
-        if (nkt > 1) {
-            stage_tile<AT, BM>(smem + STAGE_BYTES, A, lda, m0, M, kbeg + BK, kend, wave, lane, zero);
-            stage_tile<BT, BN>(smem + STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + BK, kend, wave, lane, zero);
+#pragma unroll
+        for (int p = 0; p < S - 1; ++p) {
+            if (p < nkt) {
+                stage_tile<AT, BM>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero);
+                stage_tile<BT, BN>(smem + p * STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + p * BK, kend, wave, lane, zero);
+            }
         }
         int cur = 0;                      // stage holding tile kt
         for (int kt = 0; kt < nkt; ++kt) {
-            // tile kt has landed once all but this wave's newest LOADS_PER_TILE LDS-DMA ops are done; the barrier makes
-            // every wave's share visible and proves every wave is past its reads of stage (kt+2) % 3 (= tile kt-1).
-            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_TILE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile kt has landed once all but this wave's loads of the younger in-flight tiles are done; the barrier makes
+            // every wave's share visible and proves every wave is past its reads of the stage refilled below (tile kt-1).
+            const int younger = min(S - 2, nkt - 1 - kt);
+            if (younger >= 2) wait_vmcnt<2 * LPT>();
+            else if (younger == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nkt) {
-                const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
+            if (kt + S - 1 < nkt) {
+                const int nxt = cur == 0 ? S - 1 : cur - 1;   // (cur + S - 1) % S
                 char* st = smem + nxt * STAGE_BYTES;
-                const int k0 = kbeg + (kt + 2) * BK;
+                const int k0 = kbeg + (kt + S - 1) * BK;
                 stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
                 stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
             }
             const char* sa = smem + cur * STAGE_BYTES;
             const char* sb = sa + A_BYTES;
+            bf16x8 af[MI], bfr[4];
+            load_frags4<BT, BN>(bfr, sb, wn * 64, lane);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[4], bfr[4];
-                load_frags<AT, BM>(af, sa, wm * 64, ks, lane);
-                load_frags<BT, BN>(bfr, sb, wn * 64, ks, lane);
+            for (int h = 0; h < MI / 4; ++h) load_frags4<AT, BM>(af + 4 * h, sa, wm * (MI * 16) + h * 64, lane);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            }
-            cur = cur == 2 ? 0 : cur + 1;
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+            cur = cur == S - 1 ? 0 : cur + 1;
         }
     }
 
-    // ---- epilogue: accumulators -> LDS tile -> whole rows -------------------------------------------------
+    // ---- epilogue: accumulators -> LDS (row chunks) -> whole rows -----------------------------------------
     __syncthreads();
     const int i = lane & 15, g = lane >> 4;
     constexpr bool F32_TILE = (EPI == WJ_EPI_ADD_F32 || EPI == WJ_EPI_ATOMIC_F32);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = wm * 64 + mi * 16 + i;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = wn * 64 + ni * 16 + 4 * g;
-            f32x4 v = acc[mi][ni];
-            if constexpr (F32_TILE) {
-                *reinterpret_cast<f32x4*>(smem + m * CP_F32 + n * 4) = v;
-            } else {
-                if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
-                    if (e.bias && n0 + n < N) v += *reinterpret_cast<const f32x4*>(e.bias + n0 + n);
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-                *reinterpret_cast<bf16x4*>(smem + m * CP_BF16 + n * 2) = o;
-            }
-        }
-    }
-    __syncthreads();
+    constexpr int RC = F32_TILE ? C_::RC_F32 : C_::RC_BF16;
+    constexpr int CP = F32_TILE ? C_::CP_F32 : C_::CP_BF16;
+    constexpr int NCHUNK = BM / RC;
+    constexpr int ROWS_PER_WAVE = MI * 16;
 
-    if constexpr (EPI == WJ_EPI_ATOMIC_F32) {
-        // one float per lane, a wave covers half a row: 256 contiguous bytes per atomic wave-instruction
-        const int col = t & 127, rr = t >> 7;
-        const int n = n0 + col;
-        if (n < N) {
+#pragma unroll 1
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        const int r_lo = ch * RC;
+        // -- write this chunk's rows
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mrow = wm * ROWS_PER_WAVE + mi * 16;       // wave-uniform
+            if (mrow >= r_lo && mrow < r_lo + RC) {
+                const int m = mrow - r_lo + i;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int n = wn * 64 + ni * 16 + 4 * g;
+                    f32x4 v = acc[mi][ni];
+                    if constexpr (F32_TILE) {
+                        *reinterpret_cast<f32x4*>(smem + m * CP + n * 4) = v;
+                    } else {
+                        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
+                            if (e.bias && n0 + n < N) v += *reinterpret_cast<const f32x4*>(e.bias + n0 + n);
+                        }
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                        *reinterpret_cast<bf16x4*>(smem + m * CP + n * 2) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int mh = m0 + r_lo;
+        if constexpr (EPI == WJ_EPI_ATOMIC_F32) {
+            // one float per lane: every atomic wave-instruction adds 256 contiguous bytes of one row
+            constexpr int TPR = BN;                    // threads per row
+            constexpr int RPP = NT / TPR;              // rows per pass: 2 / 4
+            const int col = t % TPR, rr = t / TPR;
+            const int n = n0 + col;
+            if (n < N) {
 #pragma unroll 8
-            for (int r = rr; r < BM; r += 4) {
-                const int m = m0 + r;
-                if (m < M) {
-                    const float v = *reinterpret_cast<const float*>(smem + r * CP_F32 + col * 4);
-                    atomicAdd((float*)e.C + (long)m * e.ldc + n, v * e.alpha);
+                for (int r = rr; r < RC; r += RPP) {
+                    const int m = mh + r;
+                    if (m < M) {
+                        const float v = *reinterpret_cast<const float*>(smem + r * CP + col * 4);
+                        atomicAdd((float*)e.C + (long)m * e.ldc + n, v * e.alpha);
+                    }
+                }
+            }
+        } else if constexpr (EPI == WJ_EPI_ADD_F32) {
+            constexpr int TPR = BN / 4;                // float4 chunks per row: 64 / 32
+            constexpr int RPP = NT / TPR;              // 8 / 16
+            constexpr int PASSES = RC / RPP;           // 8
+            const int c4 = (t % TPR) * 4, rr = t / TPR;
+            const int n = n0 + c4;
+            const bool ncol = n < N;
+            f32x4 ax[PASSES];
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {      // all addend loads in flight before the first use
+                const int m = mh + rr + RPP * ps;
+                ax[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e.aux && ncol && m < M) ax[ps] = *reinterpret_cast<const f32x4*>((const float*)e.aux + (long)m * e.ldc + n);
+            }
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int r = rr + RPP * ps, m = mh + r;
+                if (ncol && m < M) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP + c4 * 4) + ax[ps];
+                    *reinterpret_cast<f32x4*>((float*)e.C + (long)m * e.ldc + n) = v;
+                }
+            }
+        } else {
+            constexpr int TPR = BN / 8;                // 16-B chunks (8 bf16) per row: 32 / 16
+            constexpr int RPP = NT / TPR;              // 16 / 32
+            constexpr int PASSES = RC / RPP;           // 8
+            const int c8 = (t % TPR) * 8, rr = t / TPR;
+            const int n = n0 + c8;
+            const bool ncol = n < N;
+            bf16x8 hx[PASSES];
+            if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps) {
+                    const int m = mh + rr + RPP * ps;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) hx[ps][x] = f2bf(0.f);
+                    if (ncol && m < M) hx[ps] = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.aux + (long)m * e.ldc + n);
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int r = rr + RPP * ps, m = mh + r;
+                if (!(ncol && m < M)) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CP + c8 * 2);
+                const long off = (long)m * e.ldc + n;
+                if constexpr (EPI == WJ_EPI_BF16) {
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
+                } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
+                    bf16x8 gl;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
+                } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * gelu_grad_f(bf2f(hx[ps][x])));
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
+                } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
+                    const bool valid = (m % e.seg_rows) < e.seg_valid;
+                    bf16x8 pre, post;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        pre[x] = valid ? v[x] : f2bf(0.f);
+                        post[x] = valid ? f2bf(gelu_f(bf2f(v[x]))) : f2bf(0.f);
+                    }
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = pre;
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = post;
                 }
             }
         }
-    } else if constexpr (EPI == WJ_EPI_ADD_F32) {
-        const int c4 = (t & 31) * 4, rr = t >> 5;   // 32 float4 chunks per row, 16 rows per pass, 16 passes
-        const int n = n0 + c4;
-        const bool ncol = n < N;
-        f32x4 ax[16];
-#pragma unroll
-        for (int ps = 0; ps < 16; ++ps) {           // all addend loads in flight before the first use
-            const int m = m0 + rr + 16 * ps;
-            ax[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (e.aux && ncol && m < M) ax[ps] = *reinterpret_cast<const f32x4*>((const float*)e.aux + (long)m * e.ldc + n);
-        }
-#pragma unroll
-        for (int ps = 0; ps < 16; ++ps) {
-            const int r = rr + 16 * ps, m = m0 + r;
-            if (ncol && m < M) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CP_F32 + c4 * 4) + ax[ps];
-                *reinterpret_cast<f32x4*>((float*)e.C + (long)m * e.ldc + n) = v;
-            }
-        }
-    } else {
-        const int c8 = (t & 15) * 8, rr = t >> 4;   // 16 chunks of 8 bf16 per row, 32 rows per pass, 8 passes
-        const int n = n0 + c8;
-        const bool ncol = n < N;
-        bf16x8 hx[8];
-        if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
-#pragma unroll
-            for (int ps = 0; ps < 8; ++ps) {
-                const int m = m0 + rr + 32 * ps;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) hx[ps][x] = f2bf(0.f);
-                if (ncol && m < M) hx[ps] = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.aux + (long)m * e.ldc + n);
-            }
-        }
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int r = rr + 32 * ps, m = m0 + r;
-            if (!(ncol && m < M)) continue;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CP_BF16 + c8 * 2);
-            const long off = (long)m * e.ldc + n;
-            if constexpr (EPI == WJ_EPI_BF16) {
-                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
-            } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
-                bf16x8 gl;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
-                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
-                *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
-            } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
-                bf16x8 o;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * gelu_grad_f(bf2f(hx[ps][x])));
-                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
-            } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
-                const bool valid = (m % e.seg_rows) < e.seg_valid;
-                bf16x8 pre, post;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    pre[x] = valid ? v[x] : f2bf(0.f);
-                    post[x] = valid ? f2bf(gelu_f(bf2f(v[x]))) : f2bf(0.f);
-                }
-                *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = pre;
-                *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = post;
-            }
-        }
+        if (ch + 1 < NCHUNK) __syncthreads();
     }
 }
 
-template <bool AT, bool BT, int EPI>
+template <bool AT, bool BT, int EPI, int BN>
 int launch(const wj_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     int split = a->split_k < 1 ? 1 : a->split_k;
-    int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
+    int kps = ((a->K + split - 1) / split + 63) / 64 * 64;
     split = (a->K + kps - 1) / kps;
     EpiArgs e;
     e.C = a->C; e.C2 = a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
-    auto kern = gemm2_kernel<AT, BT, EPI>;
-    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    auto kern = gemm3_kernel<AT, BT, EPI, BN>;
+    constexpr int lds = Cfg<BN>::LDS_BYTES;
+    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
     const int nwg = tiles_m * tiles_n * split;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), LDS_BYTES, s, (const bf16_t*)a->A, (const bf16_t*)a->B, (long)a->lda,
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, s, (const bf16_t*)a->A, (const bf16_t*)a->B, (long)a->lda,
                        (long)a->ldb, a->M, a->N, a->K, tiles_n, split, kps, e);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }
 
+// Tile width (measured, tools/gemm_bench.py): the 256-wide tile wins when the K loop is long enough to amortise its
+// un-overlapped prologue/epilogue (split-K wgrad: 850-1030 vs 650-850 TFLOP/s); the 2-workgroup 128-wide tile wins on the
+// short-K forward / dgrad shapes (K <= 3072).  WJ_GEMM_BN=128|256 forces one (A/B runs).
+int pick_bn(const wj_gemm_args* a) {
+    static const int forced = [] { const char* v = getenv("WJ_GEMM_BN"); return v ? atoi(v) : 0; }();
+    if (forced == 128 || forced == 256) return forced;
+    return (a->epilogue == WJ_EPI_ATOMIC_F32 && a->N % 256 == 0) ? 256 : 128;
+}
+
+template <bool AT, bool BT, int EPI>
+int launch_bn(const wj_gemm_args* a, hipStream_t s) {
+    return pick_bn(a) == 256 ? launch<AT, BT, EPI, 256>(a, s) : launch<AT, BT, EPI, 128>(a, s);
+}
+
 template <bool AT, bool BT>
 int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
     switch (a->epilogue) {
-        case WJ_EPI_BF16: return launch<AT, BT, WJ_EPI_BF16>(a, s);
-        case WJ_EPI_BIAS_GELU2: return launch<AT, BT, WJ_EPI_BIAS_GELU2>(a, s);
-        case WJ_EPI_MUL_GELU_GRAD: return launch<AT, BT, WJ_EPI_MUL_GELU_GRAD>(a, s);
-        case WJ_EPI_ADD_F32: return launch<AT, BT, WJ_EPI_ADD_F32>(a, s);
-        case WJ_EPI_ATOMIC_F32: return launch<AT, BT, WJ_EPI_ATOMIC_F32>(a, s);
-        case WJ_EPI_CONV_GELU: return launch<AT, BT, WJ_EPI_CONV_GELU>(a, s);
+        case WJ_EPI_BF16: return launch_bn<AT, BT, WJ_EPI_BF16>(a, s);
+        case WJ_EPI_BIAS_GELU2: return launch_bn<AT, BT, WJ_EPI_BIAS_GELU2>(a, s);
+        case WJ_EPI_MUL_GELU_GRAD: return launch_bn<AT, BT, WJ_EPI_MUL_GELU_GRAD>(a, s);
+        case WJ_EPI_ADD_F32: return launch_bn<AT, BT, WJ_EPI_ADD_F32>(a, s);
+        case WJ_EPI_ATOMIC_F32: return launch_bn<AT, BT, WJ_EPI_ATOMIC_F32>(a, s);
+        case WJ_EPI_CONV_GELU: return launch_bn<AT, BT, WJ_EPI_CONV_GELU>(a, s);
         default: return WJ_ERR_ARG;
     }
 }

@@ -82,77 +82,106 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
     }
 }
 
-constexpr int BWD_THREADS = 512;
+constexpr int BWD_THREADS = 256;
 
+// One wave per row, TWO rows in flight per wave (independent load streams ahead of the shuffle reductions), V float4
+// chunks per lane (D <= 256 V).  Column partials (dgamma, dbeta, dbias) stay in registers across the row loop and are
+// combined through LDS atomics, then one global atomic per column per workgroup.
+template <int V>
 __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
-    __shared__ float cacc[3][1024];
+    __shared__ float cacc[3][256 * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nw = BWD_THREADS / 64;
+    constexpr int nw = BWD_THREADS / 64;
     const int D = a.D;
     const float invD = 1.0f / (float)D;
-    for (int i = threadIdx.x; i < 3 * 1024; i += BWD_THREADS) (&cacc[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * 256 * V; i += BWD_THREADS) (&cacc[0][0])[i] = 0.f;
     __syncthreads();
 
-    f32x4 dg[MAXV], db[MAXV], dbi[MAXV];
-    f32x4 gam[MAXV];
+    f32x4 dg[V], db[V], dbi[V], gam[V];
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < V; ++j) {
         dg[j] = db[j] = dbi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int col = lane * 4 + 256 * j;
         gam[j] = col < D ? *reinterpret_cast<const f32x4*>(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
-    for (int m = blockIdx.x * nw + wave; m < a.M; m += gridDim.x * nw) {
-        const long xr = remap_row(m, a.in_seg, a.in_valid);
-        const float mean = a.mean[m], rstd = a.rstd[m];
-        f32x4 xh[MAXV], dy[MAXV];
-        float c1 = 0.f, c2 = 0.f;
+    const int stride = gridDim.x * nw;
+    for (int m0 = blockIdx.x * nw + wave; m0 < a.M; m0 += 2 * stride) {
+        int mrow[2] = {m0, m0 + stride};
+        f32x4 xh[2][V], dy[2][V];
+        float mean[2], rstd[2];
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int col = lane * 4 + 256 * j;
-            xh[j] = dy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (col < D) {
-                f32x4 s = load4(a.x, xr, D, col, a.x_is_bf16);
-                if (a.r) {
-                    const bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.r + (long)m * D + col);
-                    s += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
-                }
-                dy[j] = *reinterpret_cast<const f32x4*>(a.dy + (long)m * D + col);
-                if (a.dy2) dy[j] += *reinterpret_cast<const f32x4*>(a.dy2 + (long)m * D + col);
+        for (int u = 0; u < 2; ++u) {
+            const bool live = mrow[u] < a.M;
+            const int m = live ? mrow[u] : m0;
+            const long xr = remap_row(m, a.in_seg, a.in_valid);
+            mean[u] = a.mean[m];
+            rstd[u] = a.rstd[m];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xh[j][e] = (s[e] - mean) * rstd;
-                    const float g = dy[j][e] * gam[j][e];
-                    c1 += g;
-                    c2 += g * xh[j][e];
+            for (int j = 0; j < V; ++j) {
+                const int col = lane * 4 + 256 * j;
+                xh[u][j] = dy[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (col < D) {
+                    f32x4 sx = load4(a.x, xr, D, col, a.x_is_bf16);
+                    if (a.r) {
+                        const bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.r + (long)m * D + col);
+                        sx += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+                    }
+                    f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + (long)m * D + col);
+                    if (a.dy2) d += *reinterpret_cast<const f32x4*>(a.dy2 + (long)m * D + col);
+                    xh[u][j] = sx;
+                    dy[u][j] = d;
                 }
             }
         }
-        c1 = wave_sum(c1) * invD;
-        c2 = wave_sum(c2) * invD;
-        const long orow = remap_row(m, a.out_seg, a.out_valid);
+        float c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int col = lane * 4 + 256 * j;
-            if (col < D) {
-                f32x4 ds;
-                bf16x4 dsb;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ds[e] = rstd * (dy[j][e] * gam[j][e] - c1 - xh[j][e] * c2);
-                    dsb[e] = f2bf(ds[e]);
-                    dg[j][e] += dy[j][e] * xh[j][e];
-                    db[j][e] += dy[j][e];
-                    dbi[j][e] += bf2f(dsb[e]);
+            for (int j = 0; j < V; ++j) {
+                const int col = lane * 4 + 256 * j;
+                if (col < D) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xh[u][j][e] = (xh[u][j][e] - mean[u]) * rstd[u];
+                        const float g = dy[u][j][e] * gam[j][e];
+                        c1[u] += g;
+                        c2[u] += g * xh[u][j][e];
+                    }
                 }
-                if (a.ds_f32) *reinterpret_cast<f32x4*>(a.ds_f32 + (long)m * D + col) = ds;
-                if (a.ds_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.ds_bf16 + orow * D + col) = dsb;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {      // four reductions interleaved
+            c1[0] += __shfl_xor(c1[0], o, 64); c2[0] += __shfl_xor(c2[0], o, 64);
+            c1[1] += __shfl_xor(c1[1], o, 64); c2[1] += __shfl_xor(c2[1], o, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (mrow[u] >= a.M) continue;
+            const int m = mrow[u];
+            const float k1 = c1[u] * invD, k2 = c2[u] * invD;
+            const long orow = remap_row(m, a.out_seg, a.out_valid);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int col = lane * 4 + 256 * j;
+                if (col < D) {
+                    f32x4 ds;
+                    bf16x4 dsb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ds[e] = rstd[u] * (dy[u][j][e] * gam[j][e] - k1 - xh[u][j][e] * k2);
+                        dsb[e] = f2bf(ds[e]);
+                        dg[j][e] += dy[u][j][e] * xh[u][j][e];
+                        db[j][e] += dy[u][j][e];
+                        dbi[j][e] += bf2f(dsb[e]);
+                    }
+                    if (a.ds_f32) *reinterpret_cast<f32x4*>(a.ds_f32 + (long)m * D + col) = ds;
+                    if (a.ds_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.ds_bf16 + orow * D + col) = dsb;
+                }
             }
         }
     }
-    // combine the column partials of the 8 waves in LDS, then one global atomic per column per workgroup
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < V; ++j) {
         const int col = lane * 4 + 256 * j;
         if (col < D) {
 #pragma unroll
@@ -216,9 +245,15 @@ extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if ((a->in_seg > 0 && a->in_valid <= 0) || (a->out_seg > 0 && a->out_valid <= 0)) return WJ_ERR_ARG;
     const int nw = BWD_THREADS / 64;
-    int grid = (a->M + nw - 1) / nw;
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a);
+    int grid = (a->M + 2 * nw - 1) / (2 * nw);
+    if (grid > 1536) grid = 1536;
+    const int V = (a->D + 255) / 256;
+    switch (V) {
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
+    }
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

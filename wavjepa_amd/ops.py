@@ -70,9 +70,12 @@ def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, 
          seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
 
 
-def pick_split_k(M: int, N: int, K: int, target_wgs: int = 512) -> int:
-    tiles = ((M + 255) // 256) * ((N + 127) // 128)        # the GEMM tile is 256 x 128
-    s = max(1, target_wgs // max(1, tiles))
+def pick_split_k(M: int, N: int, K: int) -> int:
+    """Split-K factor for the wgrad GEMM: fill the 256 CUs (tile 256 x 256 -> 1 workgroup/CU, 256 x 128 -> 2)."""
+    bn = 256 if N % 256 == 0 else 128           # mirrors pick_bn() in csrc/gemm.hip for the ATOMIC (wgrad) epilogue
+    tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
+    target = 256 if bn == 256 else 512
+    s = max(1, (target + tiles // 2) // max(1, tiles))
     return max(1, min(s, (K + 1023) // 1024))
 
 
