@@ -52,6 +52,8 @@ typedef struct {
     void* C2;
     const void* bias; /* f32 [N] or NULL */
     const void* aux;
+    float* colsum;    /* optional f32 [N]: += column sums of the bf16 output C (EPI_BF16 / EPI_MUL_GELU_GRAD): the bias
+                         gradient of the Linear whose output-gradient this GEMM produces, fused instead of a re-read */
     int64_t lda, ldb, ldc;
     int32_t M, N, K;
     int32_t a_trans, b_trans;
@@ -144,6 +146,7 @@ typedef struct {
     const void* dout; /* bf16 [B][T][H*hd] */
     const float* lse;
     void* dqkv;       /* bf16 [B][T][3*H*hd] */
+    float* dbias;     /* optional f32 [3*H*hd]: += column sums of dqkv over all (b, t) = in_proj_bias gradient */
     int32_t B, T, H, hd;
     int32_t mask_group;
 } wj_attn_bwd_args;

@@ -89,10 +89,15 @@ def test_gemm_dgrad_layout(ops, M, N, K):
     C32 = torch.empty(M, N, dtype=torch.float32, device=dev())
     ops.gemm(dY, W, C32, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=add)
     assert relerr(C32, ref + add) < 1e-3
-    # gelu-grad epilogue
+    # gelu-grad epilogue (+ fused column sums = bias gradient of the producing Linear)
     Hpre = rnd(M, N, dtype=torch.bfloat16, seed=10)
     Cg = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
-    ops.gemm(dY, W, Cg, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=Hpre)
+    cs = torch.ones(N, device=dev())
+    ops.gemm(dY, W, Cg, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=Hpre, colsum=cs)
+    assert relerr(cs, 1 + Cg.float().sum(0)) < 1e-4
+    cs2 = torch.zeros(N, device=dev())
+    ops.gemm(dY, W, C, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, colsum=cs2)
+    assert relerr(cs2, C.float().sum(0)) < 1e-4
     h = Hpre.float().requires_grad_(True)
     F.gelu(h).backward(ref.to(torch.bfloat16).float())
     assert relerr(Cg.float(), h.grad) < 6e-3
@@ -237,8 +242,10 @@ def test_attention_fwd_bwd(ops, B, T, H, hd):
     dout = rnd(B, T, D, dtype=torch.bfloat16, seed=32)
     ref.backward(dout.float())
     dqkv = torch.empty_like(qkv)
-    ops.attn_bwd(qkv, out, dout, lse, dqkv, B=B, T=T, H=H, hd=hd, key_mask=mask_u8)
+    dbias = torch.ones(3 * D, device=dev())
+    ops.attn_bwd(qkv, out, dout, lse, dqkv, B=B, T=T, H=H, hd=hd, key_mask=mask_u8, dbias=dbias)
     got = dqkv.float()
+    assert relerr(dbias, 1 + got.sum((0, 1))) < 1e-4             # fused in_proj_bias gradient = column sums of dqkv
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert relerr(got[..., sl], x.grad[..., sl]) < 1.5e-2, name
     # masked keys receive no gradient through k / v

@@ -22,15 +22,33 @@ template <int HD> struct Img {
     static constexpr int CH = HD / 8;       // 16-B chunks per row
 };
 
-// Copy rows [0,T) of a [T][ld] bf16 matrix (HD columns) into the padded LDS image; rows [T,KP) are zero.
+// Copy rows [0,T) of TWO [T][ld] bf16 matrices (HD columns each) into their padded LDS images; rows [T,KP) are zero.
+// All global loads of a thread are issued before its first LDS store (a load->store loop would serialise one HBM/L2
+// round trip per iteration: ~13 of them for a 200 x 64 head).
 template <int HD>
-__device__ __forceinline__ void fill_image(char* img, const bf16_t* __restrict__ src, long ld, int T, int KP) {
+__device__ __forceinline__ void fill_images2(char* img0, const bf16_t* __restrict__ src0, long ld0, char* img1,
+                                             const bf16_t* __restrict__ src1, long ld1, int T, int KP) {
     constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
-    for (int idx = threadIdx.x; idx < KP * CH; idx += blockDim.x) {
+    constexpr int MAXI = (MAX_TILES * 16 * CH + NW * 64 - 1) / (NW * 64);
+    uint4 v0[MAXI], v1[MAXI];
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int idx = threadIdx.x + it * (NW * 64);
         const int row = idx / CH, c = idx - row * CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < T) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + c * 8);
-        *reinterpret_cast<uint4*>(img + row * RS + c * 16) = v;
+        v0[it] = v1[it] = make_uint4(0, 0, 0, 0);
+        if (row < T) {
+            v0[it] = *reinterpret_cast<const uint4*>(src0 + (long)row * ld0 + c * 8);
+            v1[it] = *reinterpret_cast<const uint4*>(src1 + (long)row * ld1 + c * 8);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int idx = threadIdx.x + it * (NW * 64);
+        const int row = idx / CH, c = idx - row * CH;
+        if (row < KP) {
+            *reinterpret_cast<uint4*>(img0 + row * RS + c * 16) = v0[it];
+            *reinterpret_cast<uint4*>(img1 + row * RS + c * 16) = v1[it];
+        }
     }
 }
 
@@ -94,8 +112,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const long ld = 3L * D;
     const bf16_t* base = (const bf16_t*)a.qkv + (long)b * T * ld + h * HD;
-    fill_image<HD>(kimg, base + D, ld, T, KP);
-    fill_image<HD>(vimg, base + 2 * D, ld, T, KP);
+    bf16x8 qf[KS];                       // this wave's first query tile: in flight while K / V are staged
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, wave * 16, T, ks, lane);
+    fill_images2<HD>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
     for (int k = threadIdx.x; k < KP; k += blockDim.x)
         madd[k] = (k < T && !(km && km[k])) ? 0.f : -INFINITY;
@@ -103,9 +123,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a
 
     const float scale = rsqrtf((float)HD);
     for (int qt = wave; qt < nkt; qt += NW) {
-        bf16x8 qf[KS];
+        bf16x8 qn[KS];                   // next tile's fragments: issued now, consumed at the end of this iteration
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, qt * 16, T, ks, lane);
+        for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NW) * 16, (qt + NW < nkt) ? T : 0, ks, lane);
         f32x4 s[MAX_TILES];
         float mx = -INFINITY;
 #pragma unroll
@@ -165,6 +185,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a
             }
             if (a.lse && g == 0) a.lse[((long)b * H + h) * T + q] = sum > 0.f ? msafe + __logf(sum) : INFINITY;
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
     }
 }
 
@@ -180,6 +202,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
     float* lse_s = reinterpret_cast<float*>(smem + 2 * KP * RS);  // [KP]  (+inf for rows >= T)
     float* delta = lse_s + KP;                                     // [KP]
     float* kvalid = delta + KP;                                    // [KP]  1 = key attended, 0 = masked / padding
+    float* bsum = kvalid + KP;                                     // [3*HD] column sums of dq | dk | dv (in_proj_bias grad)
+    for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) bsum[x] = 0.f;
 
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
@@ -190,8 +214,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
     bf16_t* dqkv = (bf16_t*)a.dqkv + (long)b * T * ld + h * HD;
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
-    fill_image<HD>(img0, qkv + D, ld, T, KP);
-    fill_image<HD>(img1, qkv + 2 * D, ld, T, KP);
+    fill_images2<HD>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
         float l = INFINITY, dl = 0.f, kv = 0.f;
         if (r < T) {
@@ -212,12 +235,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- phase A: dQ for 16 queries per wave iteration (queries on the lane, keys on the accumulator rows)
+    f32x4 csq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) csq[dt] = zero4;
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = row_frag_global(qkv, ld, wave * 16, T, ks, lane);
+        dof[ks] = row_frag_global(dO, D, wave * 16, T, ks, lane);
+    }
     for (int qt = wave; qt < nt; qt += NW) {
-        bf16x8 qf[KS], dof[KS];
+        bf16x8 qn[KS], don[KS];          // prefetch of the next query tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = row_frag_global(qkv, ld, qt * 16, T, ks, lane);
-            dof[ks] = row_frag_global(dO, D, qt * 16, T, ks, lane);
+            qn[ks] = row_frag_global(qkv, ld, (qt + NW) * 16, (qt + NW < nt) ? T : 0, ks, lane);
+            don[ks] = row_frag_global(dO, D, (qt + NW) * 16, (qt + NW < nt) ? T : 0, ks, lane);
         }
         const float my_lse = lse_s[qt * 16 + i], my_delta = delta[qt * 16 + i];
         f32x4 dq[DT];
@@ -258,23 +290,43 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
             for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 ov;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = f2bf(dq[dt][r]);
+                for (int r = 0; r < 4; ++r) { ov[r] = f2bf(dq[dt][r]); csq[dt][r] += bf2f(ov[r]); }
                 *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[ks] = qn[ks]; dof[ks] = don[ks]; }
+    }
+    if (a.dbias) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = csq[dt][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (i == 0) atomicAdd(bsum + dt * 16 + 4 * g + r, v);
+            }
     }
     __syncthreads();
-    fill_image<HD>(img0, qkv, ld, T, KP);
-    fill_image<HD>(img1, dO, D, T, KP);
+    fill_images2<HD>(img0, qkv, ld, img1, dO, D, T, KP);
     __syncthreads();
 
     // ---- phase B: dK, dV for 16 keys per wave iteration (keys on the lane, queries on the accumulator rows)
+    f32x4 csk[DT], csv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) csk[dt] = csv[dt] = zero4;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = row_frag_global(qkv + D, ld, wave * 16, T, ks, lane);
+        vf[ks] = row_frag_global(qkv + 2 * D, ld, wave * 16, T, ks, lane);
+    }
     for (int kt = wave; kt < nt; kt += NW) {
-        bf16x8 kf[KS], vf[KS];
+        bf16x8 kn[KS], vn[KS];           // prefetch of the next key tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = row_frag_global(qkv + D, ld, kt * 16, T, ks, lane);
-            vf[ks] = row_frag_global(qkv + 2 * D, ld, kt * 16, T, ks, lane);
+            kn[ks] = row_frag_global(qkv + D, ld, (kt + NW) * 16, (kt + NW < nt) ? T : 0, ks, lane);
+            vn[ks] = row_frag_global(qkv + 2 * D, ld, (kt + NW) * 16, (kt + NW < nt) ? T : 0, ks, lane);
         }
         const float my_kv = kvalid[kt * 16 + i];
         f32x4 dk[DT], dv[DT];
@@ -320,10 +372,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
             for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 ok, ov;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dk[dt][r]); ov[r] = f2bf(dv[dt][r]); }
+                for (int r = 0; r < 4; ++r) {
+                    ok[r] = f2bf(dk[dt][r]); ov[r] = f2bf(dv[dt][r]);
+                    csk[dt][r] += bf2f(ok[r]); csv[dt][r] += bf2f(ov[r]);
+                }
                 *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
                 *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
             }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+    }
+    if (a.dbias) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = csk[dt][r], u = csv[dt][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                u += __shfl_xor(u, 1, 64); u += __shfl_xor(u, 2, 64); u += __shfl_xor(u, 4, 64); u += __shfl_xor(u, 8, 64);
+                if (i == 0) {
+                    atomicAdd(bsum + HD + dt * 16 + 4 * g + r, v);
+                    atomicAdd(bsum + 2 * HD + dt * 16 + 4 * g + r, u);
+                }
+            }
+        __syncthreads();
+        for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) {
+            const int part = x / HD, d = x - part * HD;
+            atomicAdd(a.dbias + part * D + h * HD + d, bsum[x]);
         }
     }
 }
@@ -360,14 +436,14 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     const int KP = ((a->T + 31) / 32) * 32;
-    const int lds = 2 * KP * (a->hd * 2 + 32) + 3 * KP * 4;
+    const int lds = 2 * KP * (a->hd * 2 + 32) + 3 * KP * 4 + 3 * a->hd * 4;
     dim3 grid(a->B * a->H), block(NW * 64);
     if (a->hd == 64) {
-        static int once = set_lds(attn_bwd_kernel<64>, 2 * 224 * 160 + 3 * 224 * 4);
+        static int once = set_lds(attn_bwd_kernel<64>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4);
         (void)once;
         hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, lds, (hipStream_t)stream, *a);
     } else {
-        static int once = set_lds(attn_bwd_kernel<32>, 2 * 224 * 96 + 3 * 224 * 4);
+        static int once = set_lds(attn_bwd_kernel<32>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4);
         (void)once;
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, lds, (hipStream_t)stream, *a);
     }

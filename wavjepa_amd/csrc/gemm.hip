@@ -145,6 +145,7 @@ struct EpiArgs {
     void* C2;
     const float* bias;
     const void* aux;
+    float* colsum;
     long ldc;
     int seg_rows, seg_valid;
     float alpha;
@@ -305,6 +306,8 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
             const int n = n0 + c8;
             const bool ncol = n < N;
             bf16x8 hx[PASSES];
+            float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            constexpr bool CS = (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_MUL_GELU_GRAD);
             if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
 #pragma unroll
                 for (int ps = 0; ps < PASSES; ++ps) {
@@ -322,6 +325,10 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                 const long off = (long)m * e.ldc + n;
                 if constexpr (EPI == WJ_EPI_BF16) {
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
+                    if (e.colsum) {
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) csum[x] += bf2f(v[x]);
+                    }
                 } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
                     bf16x8 gl;
 #pragma unroll
@@ -333,6 +340,10 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
 #pragma unroll
                     for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * gelu_grad_f(bf2f(hx[ps][x])));
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
+                    if (e.colsum) {
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) csum[x] += bf2f(o[x]);
+                    }
                 } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
                     const bool valid = (m % e.seg_rows) < e.seg_valid;
                     bf16x8 pre, post;
@@ -343,6 +354,30 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                     }
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = pre;
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = post;
+                }
+            }
+            if constexpr (CS) {
+                if (e.colsum) {   // kernel-uniform: fold this chunk's column partials (threads t, t+TPR, ... share a column chunk)
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+#pragma unroll
+                        for (int o = TPR; o < 64; o <<= 1) csum[x] += __shfl_xor(csum[x], o, 64);
+                    }
+                    __syncthreads();                                  // all reads of the staged C tile are done
+                    float* cs = reinterpret_cast<float*>(smem);       // [8 waves][BN]
+                    if (lane < TPR && ncol) {
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) cs[wave * BN + c8 + x] = csum[x];
+                    }
+                    __syncthreads();
+                    if (t < BN && n0 + t < N) {
+                        float tot = 0.f;
+#pragma unroll
+                        for (int wv = 0; wv < 8; ++wv) tot += cs[wv * BN + t];
+                        atomicAdd(e.colsum + n0 + t, tot);
+                    }
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) csum[x] = 0.f;
                 }
             }
         }
@@ -357,7 +392,7 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     int kps = ((a->K + split - 1) / split + 63) / 64 * 64;
     split = (a->K + kps - 1) / kps;
     EpiArgs e;
-    e.C = a->C; e.C2 = a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc;
+    e.C = a->C; e.C2 = a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc; e.colsum = a->colsum;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
     auto kern = gemm3_kernel<AT, BT, EPI, BN>;
@@ -410,6 +445,7 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if ((a->epilogue == WJ_EPI_BIAS_GELU2 || a->epilogue == WJ_EPI_CONV_GELU) && !a->C2) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD && !a->aux) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
+    if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;
     static const bool use_v1 = getenv("WJ_GEMM_V1") != nullptr;
     if (use_v1) return wj_gemm_bf16_v1(a, stream);
     hipStream_t s = (hipStream_t)stream;

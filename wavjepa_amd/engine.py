@@ -301,15 +301,14 @@ class JepaEngine:
         ds, dsb, dh, dx1, do, dqkv = bw["ds"], bw["dsb"], bw["dh"], bw["dx1"], bw["do"], bw["dqkv"]
         ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2)
         self._wgrad(dsb, a.g, w.gw2, D, 4 * D, M)
-        ops.gemm(dsb, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h)
-        ops.colsum_bf16(dh, w.gb1, M=M, N=4 * D, ldx=4 * D)
+        ops.gemm(dsb, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
+                 colsum=w.gb1)           # linear1.bias gradient = column sums of dh, fused into the producing epilogue
         self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
         ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
         ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo)
         self._wgrad(dsb, a.o, w.gwo, D, D, M)
         ops.gemm(dsb, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
-        ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask)
-        ops.colsum_bf16(dqkv, w.gbqkv, M=M, N=3 * D, ldx=3 * D)
+        ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv)
         self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, M)
         ops.gemm(dqkv, w.wqkv, dx_out, M=M, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
 

@@ -64,8 +64,8 @@ def require_gpu() -> None:
 # ---------------------------------------------------------------------------------------------------------- GEMM
 def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, a_trans: int = 0,
          b_trans: int = 0, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, aux: Ptr = None, split_k: int = 1,
-         seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, stream: Optional[int] = None) -> None:
-    _run("wj_gemm_bf16", "wj_gemm_args", stream, A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), aux=_p(aux),
+         seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, colsum: Ptr = None, stream: Optional[int] = None) -> None:
+    _run("wj_gemm_bf16", "wj_gemm_args", stream, A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), aux=_p(aux), colsum=_p(colsum),
          lda=lda, ldb=ldb, ldc=ldc, M=M, N=N, K=K, a_trans=a_trans, b_trans=b_trans, epilogue=epilogue, split_k=split_k,
          seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
 
@@ -110,9 +110,9 @@ def attn_fwd(qkv: Ptr, out: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: P
 
 
 def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None,
-             mask_group: int = 1, stream: Optional[int] = None) -> None:
+             mask_group: int = 1, dbias: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_attn_bwd", "wj_attn_bwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), out=_p(out), dout=_p(dout),
-         lse=_p(lse), dqkv=_p(dqkv), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
+         lse=_p(lse), dqkv=_p(dqkv), dbias=_p(dbias), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
 
 
 # ---------------------------------------------------------------------------------------------------------- conv front-end
