@@ -105,6 +105,8 @@ typedef struct {
     float* dgamma;
     float* dbeta;
     float* dbias;
+    float* workspace; /* optional f32 [1536][3][D]: per-workgroup partials (plain stores) folded by a second kernel
+                         instead of ~1500 contended atomics per column */
     int32_t M, D;
     int32_t x_is_bf16;
     int32_t in_seg, in_valid;
@@ -120,6 +122,8 @@ typedef struct {
     int32_t M, N;
 } wj_colsum_args;
 int wj_colsum_bf16(const wj_colsum_args*, void* stream);
+/* same for an f32 matrix (x: f32 [M][N], ldx in elements): folds per-workgroup partial sums */
+int wj_colsum_f32(const wj_colsum_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-head self-attention with a key-padding mask, forward and backward.
@@ -147,6 +151,7 @@ typedef struct {
     const float* lse;
     void* dqkv;       /* bf16 [B][T][3*H*hd] */
     float* dbias;     /* optional f32 [3*H*hd]: += column sums of dqkv over all (b, t) = in_proj_bias gradient */
+    float* dbias_ws;  /* f32 [B][3*H*hd] scratch, required with dbias: per-(b,h) partials, folded by a second kernel */
     int32_t B, T, H, hd;
     int32_t mask_group;
 } wj_attn_bwd_args;

@@ -168,6 +168,11 @@ def test_layernorm_fwd_bwd(ops, M, D):
     dbeta = torch.zeros(D, device=dev())
     dbias = torch.zeros(D, device=dev())
     ops.layernorm_bwd(dy, x, gamma, mean, rstd, M=M, D=D, r=r, ds_f32=ds, ds_bf16=dsb, dgamma=dgamma, dbeta=dbeta, dbias=dbias)
+    # two-stage variant (workspace partials + fold kernel) must agree with the atomic variant
+    dg2, db2, dbi2 = torch.zeros(D, device=dev()), torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    wsp = torch.empty(1536 * 3 * D, device=dev())
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, M=M, D=D, r=r, ds_f32=ds, ds_bf16=dsb, dgamma=dg2, dbeta=db2, dbias=dbi2, workspace=wsp)
+    assert relerr(dg2, dgamma) < 1e-5 and relerr(db2, dbeta) < 1e-5 and relerr(dbi2, dbias) < 1e-5
     assert relerr(ds, xr.grad) < 2e-5
     assert relerr(dgamma, g2.grad) < 2e-5
     assert relerr(dbeta, b2.grad) < 2e-5
@@ -243,7 +248,8 @@ def test_attention_fwd_bwd(ops, B, T, H, hd):
     ref.backward(dout.float())
     dqkv = torch.empty_like(qkv)
     dbias = torch.ones(3 * D, device=dev())
-    ops.attn_bwd(qkv, out, dout, lse, dqkv, B=B, T=T, H=H, hd=hd, key_mask=mask_u8, dbias=dbias)
+    ws = torch.empty(B, 3 * D, device=dev())
+    ops.attn_bwd(qkv, out, dout, lse, dqkv, B=B, T=T, H=H, hd=hd, key_mask=mask_u8, dbias=dbias, dbias_ws=ws)
     got = dqkv.float()
     assert relerr(dbias, 1 + got.sum((0, 1))) < 1e-4             # fused in_proj_bias gradient = column sums of dqkv
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):

@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip.h")
-LIB_PATH = os.path.join(HERE, "lib", "libwavjepa_hip.so")
+LIB_PATH = os.environ.get("WAVJEPA_HIP_LIB") or os.path.join(HERE, "lib", "libwavjepa_hip.so")   # override: A/B and ablation builds
 
 _SCALARS = {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "int": ctypes.c_int}
 

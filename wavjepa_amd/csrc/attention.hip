@@ -15,7 +15,8 @@
 namespace {
 
 constexpr int MAX_TILES = 14;  // 16-row tiles: T <= 224
-constexpr int NW = 4;          // waves per workgroup
+constexpr int NWB64 = 4, NWB32 = 4;   // backward waves per workgroup (more waves measured slower: 339 -> 439 us at hd 64)
+constexpr int NWF = 7;         // forward: 13 query tiles over 7 waves (2,2,2,2,2,2,1) instead of 4 (4,3,3,3)
 
 template <int HD> struct Img {
     static constexpr int RS = HD * 2 + 32;  // padded row stride in bytes
@@ -25,15 +26,15 @@ template <int HD> struct Img {
 // Copy rows [0,T) of TWO [T][ld] bf16 matrices (HD columns each) into their padded LDS images; rows [T,KP) are zero.
 // All global loads of a thread are issued before its first LDS store (a load->store loop would serialise one HBM/L2
 // round trip per iteration: ~13 of them for a 200 x 64 head).
-template <int HD>
+template <int HD, int NWAVES>
 __device__ __forceinline__ void fill_images2(char* img0, const bf16_t* __restrict__ src0, long ld0, char* img1,
                                              const bf16_t* __restrict__ src1, long ld1, int T, int KP) {
     constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
-    constexpr int MAXI = (MAX_TILES * 16 * CH + NW * 64 - 1) / (NW * 64);
+    constexpr int MAXI = (MAX_TILES * 16 * CH + NWAVES * 64 - 1) / (NWAVES * 64);
     uint4 v0[MAXI], v1[MAXI];
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
-        const int idx = threadIdx.x + it * (NW * 64);
+        const int idx = threadIdx.x + it * (NWAVES * 64);
         const int row = idx / CH, c = idx - row * CH;
         v0[it] = v1[it] = make_uint4(0, 0, 0, 0);
         if (row < T) {
@@ -43,7 +44,7 @@ __device__ __forceinline__ void fill_images2(char* img0, const bf16_t* __restric
     }
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
-        const int idx = threadIdx.x + it * (NW * 64);
+        const int idx = threadIdx.x + it * (NWAVES * 64);
         const int row = idx / CH, c = idx - row * CH;
         if (row < KP) {
             *reinterpret_cast<uint4*>(img0 + row * RS + c * 16) = v0[it];
@@ -99,7 +100,7 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a) {
+__global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = a.T, H = a.H, D = H * HD;
@@ -115,17 +116,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a
     bf16x8 qf[KS];                       // this wave's first query tile: in flight while K / V are staged
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, wave * 16, T, ks, lane);
-    fill_images2<HD>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
+    fill_images2<HD, NWF>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
     for (int k = threadIdx.x; k < KP; k += blockDim.x)
         madd[k] = (k < T && !(km && km[k])) ? 0.f : -INFINITY;
     __syncthreads();
 
     const float scale = rsqrtf((float)HD);
-    for (int qt = wave; qt < nkt; qt += NW) {
+    for (int qt = wave; qt < nkt; qt += NWF) {
         bf16x8 qn[KS];                   // next tile's fragments: issued now, consumed at the end of this iteration
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NW) * 16, (qt + NW < nkt) ? T : 0, ks, lane);
+        for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NWF) * 16, (qt + NWF < nkt) ? T : 0, ks, lane);
         f32x4 s[MAX_TILES];
         float mx = -INFINITY;
 #pragma unroll
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(wj_attn_fwd_args a
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int HD>
-__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a) {
+template <int HD, int NWB>
+__global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj_attn_bwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = a.T, H = a.H, D = H * HD;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
     bf16_t* dqkv = (bf16_t*)a.dqkv + (long)b * T * ld + h * HD;
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
-    fill_images2<HD>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
+    fill_images2<HD, NWB>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
         float l = INFINITY, dl = 0.f, kv = 0.f;
         if (r < T) {
@@ -244,12 +245,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
         qf[ks] = row_frag_global(qkv, ld, wave * 16, T, ks, lane);
         dof[ks] = row_frag_global(dO, D, wave * 16, T, ks, lane);
     }
-    for (int qt = wave; qt < nt; qt += NW) {
+    for (int qt = wave; qt < nt; qt += NWB) {
         bf16x8 qn[KS], don[KS];          // prefetch of the next query tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qn[ks] = row_frag_global(qkv, ld, (qt + NW) * 16, (qt + NW < nt) ? T : 0, ks, lane);
-            don[ks] = row_frag_global(dO, D, (qt + NW) * 16, (qt + NW < nt) ? T : 0, ks, lane);
+            qn[ks] = row_frag_global(qkv, ld, (qt + NWB) * 16, (qt + NWB < nt) ? T : 0, ks, lane);
+            don[ks] = row_frag_global(dO, D, (qt + NWB) * 16, (qt + NWB < nt) ? T : 0, ks, lane);
         }
         const float my_lse = lse_s[qt * 16 + i], my_delta = delta[qt * 16 + i];
         f32x4 dq[DT];
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
             }
     }
     __syncthreads();
-    fill_images2<HD>(img0, qkv, ld, img1, dO, D, T, KP);
+    fill_images2<HD, NWB>(img0, qkv, ld, img1, dO, D, T, KP);
     __syncthreads();
 
     // ---- phase B: dK, dV for 16 keys per wave iteration (keys on the lane, queries on the accumulator rows)
@@ -321,12 +322,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
         kf[ks] = row_frag_global(qkv + D, ld, wave * 16, T, ks, lane);
         vf[ks] = row_frag_global(qkv + 2 * D, ld, wave * 16, T, ks, lane);
     }
-    for (int kt = wave; kt < nt; kt += NW) {
+    for (int kt = wave; kt < nt; kt += NWB) {
         bf16x8 kn[KS], vn[KS];           // prefetch of the next key tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kn[ks] = row_frag_global(qkv + D, ld, (kt + NW) * 16, (kt + NW < nt) ? T : 0, ks, lane);
-            vn[ks] = row_frag_global(qkv + 2 * D, ld, (kt + NW) * 16, (kt + NW < nt) ? T : 0, ks, lane);
+            kn[ks] = row_frag_global(qkv + D, ld, (kt + NWB) * 16, (kt + NWB < nt) ? T : 0, ks, lane);
+            vn[ks] = row_frag_global(qkv + 2 * D, ld, (kt + NWB) * 16, (kt + NWB < nt) ? T : 0, ks, lane);
         }
         const float my_kv = kvalid[kt * 16 + i];
         f32x4 dk[DT], dv[DT];
@@ -397,9 +398,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(wj_attn_bwd_args a
                 }
             }
         __syncthreads();
+        // per-(b, h) partials with plain stores; wj_attn_bwd folds the B rows afterwards (atomics from every workgroup
+        // into the same 3*D addresses cost 70-80 us per launch)
         for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) {
             const int part = x / HD, d = x - part * HD;
-            atomicAdd(a.dbias + part * D + h * HD + d, bsum[x]);
+            a.dbias_ws[(long)b * 3 * D + part * D + h * HD + d] = bsum[x];
         }
     }
 }
@@ -417,7 +420,7 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     const int KP = ((a->T + 31) / 32) * 32;
     const int lds = 2 * KP * (a->hd * 2 + 32) + KP * 4;
-    dim3 grid(a->B * a->H), block(NW * 64);
+    dim3 grid(a->B * a->H), block(NWF * 64);
     if (a->hd == 64) {
         static int once = set_lds(attn_fwd_kernel<64>, 2 * 224 * 160 + 224 * 4);
         (void)once;
@@ -435,17 +438,24 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->dqkv) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    if (a->dbias && !a->dbias_ws) return WJ_ERR_ARG;
     const int KP = ((a->T + 31) / 32) * 32;
     const int lds = 2 * KP * (a->hd * 2 + 32) + 3 * KP * 4 + 3 * a->hd * 4;
-    dim3 grid(a->B * a->H), block(NW * 64);
+    dim3 grid(a->B * a->H);
     if (a->hd == 64) {
-        static int once = set_lds(attn_bwd_kernel<64>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4);
+        static int once = set_lds(attn_bwd_kernel<64, NWB64>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, lds, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64>), grid, dim3(NWB64 * 64), lds, (hipStream_t)stream, *a);
     } else {
-        static int once = set_lds(attn_bwd_kernel<32>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4);
+        static int once = set_lds(attn_bwd_kernel<32, NWB32>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, lds, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32>), grid, dim3(NWB32 * 64), lds, (hipStream_t)stream, *a);
+    }
+    if (a->dbias) {
+        wj_colsum_args c;
+        c.x = a->dbias_ws; c.out = a->dbias; c.ldx = 3L * a->H * a->hd; c.M = a->B; c.N = 3 * a->H * a->hd;
+        const int rc = wj_colsum_f32(&c, stream);
+        if (rc != WJ_OK) return rc;
     }
     WJ_CHECK_LAUNCH();
     return WJ_OK;

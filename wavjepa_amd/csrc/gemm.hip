@@ -156,11 +156,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool AT, bool BT, int EPI, int BN>
+template <bool AT, bool BT, int EPI, int BN, bool STAGGER>
 __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                                       long lda, long ldb, int M, int N, int K, int tiles_n,
                                                                       int split_k, int k_per_split, EpiArgs e) {
     using C_ = Cfg<BN>;
+    static_assert(!STAGGER || BN == 256, "the ping-pong schedule is built for the 8-wave 256x256 tile");
     constexpr int S = C_::STAGES, A_BYTES = C_::A_BYTES, STAGE_BYTES = C_::STAGE_BYTES, LPT = C_::LOADS_PER_TILE, MI = C_::MI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -192,39 +193,111 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
             }
         }
         int cur = 0;                      // stage holding tile kt
-        for (int kt = 0; kt < nkt; ++kt) {
-            // tile kt has landed once all but this wave's loads of the younger in-flight tiles are done; the barrier makes
-            // every wave's share visible and proves every wave is past its reads of the stage refilled below (tile kt-1).
-            const int younger = min(S - 2, nkt - 1 - kt);
-            if (younger >= 2) wait_vmcnt<2 * LPT>();
-            else if (younger == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + S - 1 < nkt) {
-                const int nxt = cur == 0 ? S - 1 : cur - 1;   // (cur + S - 1) % S
-                char* st = smem + nxt * STAGE_BYTES;
-                const int k0 = kbeg + (kt + S - 1) * BK;
-                stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
-                stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+        if constexpr (!STAGGER) {
+            for (int kt = 0; kt < nkt; ++kt) {
+                // tile kt has landed once all but this wave's loads of the younger in-flight tiles are done; the barrier makes
+                // every wave's share visible and proves every wave is past its reads of the stage refilled below (tile kt-1).
+                const int younger = min(S - 2, nkt - 1 - kt);
+                if (younger >= 2) wait_vmcnt<2 * LPT>();
+                else if (younger == 1) wait_vmcnt<LPT>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (kt + S - 1 < nkt) {
+                    const int nxt = cur == 0 ? S - 1 : cur - 1;   // (cur + S - 1) % S
+                    char* st = smem + nxt * STAGE_BYTES;
+                    const int k0 = kbeg + (kt + S - 1) * BK;
+                    stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
+                    stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+                }
+                const char* sa = smem + cur * STAGE_BYTES;
+                const char* sb = sa + A_BYTES;
+                bf16x8 af[MI], bfr[4];
+                load_frags4<BT, BN>(bfr, sb, wn * 64, lane);
+#pragma unroll
+                for (int h = 0; h < MI / 4; ++h) load_frags4<AT, BM>(af + 4 * h, sa, wm * (MI * 16) + h * 64, lane);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                cur = cur == S - 1 ? 0 : cur + 1;
             }
-            const char* sa = smem + cur * STAGE_BYTES;
-            const char* sb = sa + A_BYTES;
-            bf16x8 af[MI], bfr[4];
-            load_frags4<BT, BN>(bfr, sb, wn * 64, lane);
+        } else {
+            // Ping-pong: waves 0-3 (group 0) and 4-7 (group 1) share the four SIMDs pairwise and run the same
+            // LOAD / COMPUTE segments one barrier apart, so on every SIMD one wave issues its 32-MFMA cluster while its
+            // partner issues the next LDS-DMA tile and reads its fragments.  Two barriers per K tile; every wave waits
+            // (counted vmcnt) for tile kt+1 in the segment before group 0 starts reading it.
+            // (Interleaving the LDS-DMA issue into the MFMA cluster instead was measured slower: ceiling 1133 -> 843 TFLOP/s.)
+            const int grp = wave >> 2;
+            {   // tile 0 landed and visible
+                const int younger = min(S - 2, nkt - 1);
+                if (younger >= 2) wait_vmcnt<2 * LPT>();
+                else if (younger == 1) wait_vmcnt<LPT>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 starts one segment later
+            for (int kt = 0; kt < nkt; ++kt) {
+                // ---- LOAD segment
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef WJ_ABLATE_GLDS
+                if (kt + S - 1 < nkt) {
+                    const int nxt = cur == 0 ? S - 1 : cur - 1;   // stage of tile kt-1: both groups read it >= 1 barrier ago
+                    char* st = smem + nxt * STAGE_BYTES;
+                    const int k0 = kbeg + (kt + S - 1) * BK;
+                    stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
+                    stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+                }
+#endif
+                const char* sa = smem + cur * STAGE_BYTES;
+                const char* sb = sa + A_BYTES;
+                bf16x8 af[MI], bfr[4];
+                load_frags4<BT, BN>(bfr, sb, wn * 64, lane);
 #pragma unroll
-            for (int h = 0; h < MI / 4; ++h) load_frags4<AT, BM>(af + 4 * h, sa, wm * (MI * 16) + h * 64, lane);
+                for (int h = 0; h < MI / 4; ++h) load_frags4<AT, BM>(af + 4 * h, sa, wm * (MI * 16) + h * 64, lane);
+                const int younger = min(S - 2, nkt - 2 - kt);   // tiles younger than kt+1 still allowed in flight
+                if (grp == 1 && kt + 1 < nkt) {
+                    if (younger >= 2) wait_vmcnt<2 * LPT>();
+                    else if (younger == 1) wait_vmcnt<LPT>();
+                    else wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                // ---- COMPUTE segment
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
-            cur = cur == S - 1 ? 0 : cur + 1;
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (grp == 0 && kt + 1 < nkt) {
+                    if (younger >= 2) wait_vmcnt<2 * LPT>();
+                    else if (younger == 1) wait_vmcnt<LPT>();
+                    else wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                cur = cur == S - 1 ? 0 : cur + 1;
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();       // balance the stagger
         }
     }
 
     // ---- epilogue: accumulators -> LDS (row chunks) -> whole rows -----------------------------------------
-    __syncthreads();
     const int i = lane & 15, g = lane >> 4;
+    // bias fragments: all four loads issued together BEFORE the barrier (inside the fragment loops they were serialised
+    // L2 round trips: 25-35 us per launch on the QKV shape)
+    f32x4 bv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
+            const int n = n0 + wn * 64 + ni * 16 + 4 * g;
+            if (e.bias && n < N) bv[ni] = *reinterpret_cast<const f32x4*>(e.bias + n);
+        }
+    }
+    __syncthreads();
     constexpr bool F32_TILE = (EPI == WJ_EPI_ADD_F32 || EPI == WJ_EPI_ATOMIC_F32);
     constexpr int RC = F32_TILE ? C_::RC_F32 : C_::RC_BF16;
     constexpr int CP = F32_TILE ? C_::CP_F32 : C_::CP_BF16;
@@ -247,9 +320,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                     if constexpr (F32_TILE) {
                         *reinterpret_cast<f32x4*>(smem + m * CP + n * 4) = v;
                     } else {
-                        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
-                            if (e.bias && n0 + n < N) v += *reinterpret_cast<const f32x4*>(e.bias + n0 + n);
-                        }
+                        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) v += bv[ni];
                         bf16x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -385,7 +456,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     }
 }
 
-template <bool AT, bool BT, int EPI, int BN>
+template <bool AT, bool BT, int EPI, int BN, bool STAGGER>
 int launch(const wj_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     int split = a->split_k < 1 ? 1 : a->split_k;
@@ -395,7 +466,7 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     e.C = a->C; e.C2 = a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc; e.colsum = a->colsum;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
-    auto kern = gemm3_kernel<AT, BT, EPI, BN>;
+    auto kern = gemm3_kernel<AT, BT, EPI, BN, STAGGER>;
     constexpr int lds = Cfg<BN>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
@@ -406,18 +477,27 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     return WJ_OK;
 }
 
-// Tile width (measured, tools/gemm_bench.py): the 256-wide tile wins when the K loop is long enough to amortise its
-// un-overlapped prologue/epilogue (split-K wgrad: 850-1030 vs 650-850 TFLOP/s); the 2-workgroup 128-wide tile wins on the
-// short-K forward / dgrad shapes (K <= 3072).  WJ_GEMM_BN=128|256 forces one (A/B runs).
-int pick_bn(const wj_gemm_args* a) {
-    static const int forced = [] { const char* v = getenv("WJ_GEMM_BN"); return v ? atoi(v) : 0; }();
-    if (forced == 128 || forced == 256) return forced;
-    return (a->epilogue == WJ_EPI_ATOMIC_F32 && a->N % 256 == 0) ? 256 : 128;
+// Variant selection, from tools/gemm_bench.py / tools/gemm_overhead.py on MI355X:
+//   0 = 256x128 tile, 2 workgroups/CU    : short K, VALU-heavy epilogues (GELU), dgrad (col-form B), N % 256 != 0
+//   1 = 256x256 tile, plain schedule     : split-K wgrad (long K loop; 850-1000 TFLOP/s)
+//   2 = 256x256 tile, ping-pong schedule : forward / conv shapes with plain epilogues and K >= 512 (+9..17 % over variant 0)
+// WJ_GEMM_VARIANT=0|1|2 forces one (A/B runs; 1 and 2 need N % 256 == 0 to avoid wasted columns but stay correct).
+int pick_variant(const wj_gemm_args* a) {
+    static const int forced = [] { const char* v = getenv("WJ_GEMM_VARIANT"); return v ? atoi(v) : -1; }();
+    if (forced >= 0 && forced <= 2) return forced;
+    if (a->N % 256 != 0) return 0;
+    if (a->epilogue == WJ_EPI_ATOMIC_F32) return 1;
+    if (!a->a_trans && !a->b_trans && a->K >= 512 && (a->epilogue == WJ_EPI_BF16 || a->epilogue == WJ_EPI_CONV_GELU)) return 2;
+    return 0;
 }
 
 template <bool AT, bool BT, int EPI>
 int launch_bn(const wj_gemm_args* a, hipStream_t s) {
-    return pick_bn(a) == 256 ? launch<AT, BT, EPI, 256>(a, s) : launch<AT, BT, EPI, 128>(a, s);
+    switch (pick_variant(a)) {
+        case 1: return launch<AT, BT, EPI, 256, false>(a, s);
+        case 2: return launch<AT, BT, EPI, 256, true>(a, s);
+        default: return launch<AT, BT, EPI, 128, false>(a, s);
+    }
 }
 
 template <bool AT, bool BT>

@@ -193,11 +193,55 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
         }
     }
     __syncthreads();
+    if (a.workspace) {   // plain coalesced stores of this workgroup's partials; a second kernel folds them
+        float* ws = a.workspace + (long)blockIdx.x * 3 * D;
+        for (int c = threadIdx.x; c < 3 * D; c += BWD_THREADS) ws[c] = cacc[c / D][c % D];
+        return;
+    }
     for (int c = threadIdx.x; c < D; c += BWD_THREADS) {
         if (a.dgamma) atomicAdd(a.dgamma + c, cacc[0][c]);
         if (a.dbeta) atomicAdd(a.dbeta + c, cacc[1][c]);
         if (a.dbias) atomicAdd(a.dbias + c, cacc[2][c]);
     }
+}
+
+// out[c] += sum over rows of an f32 matrix: workgroup = 128 columns x a row range (float4 per thread, 8 row lanes)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, long ldx, int M, int N,
+                                                         float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
+                                                         int n_each, int rows_per_wg) {
+    __shared__ float red[8][132];
+    const int t = threadIdx.x, cc = t & 31, rl = t >> 5;
+    const int col = blockIdx.x * 128 + cc * 4;
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (col < N)
+        for (int r = r0 + rl; r < r1; r += 8) acc += *reinterpret_cast<const f32x4*>(x + (long)r * ldx + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cc * 4 + e] = acc[e];
+    __syncthreads();
+    if (t < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][t];
+        const int c = blockIdx.x * 128 + t;
+        if (c < N) {
+            // columns [0, n_each) -> o0, [n_each, 2 n_each) -> o1, ... (LayerNorm's three gradients share one launch)
+            const int which = c / n_each, cc2 = c - which * n_each;
+            float* o = which == 0 ? o0 : (which == 1 ? o1 : o2);
+            if (o) atomicAdd(o + cc2, s);
+        }
+    }
+}
+
+void launch_colsum_f32(const float* x, long ldx, int M, int N, float* o0, float* o1, float* o2, int n_each, hipStream_t s) {
+    const int gx = (N + 127) / 128;
+    int gy = 1024 / gx;               // ~1000 workgroups: a thread sums only a handful of rows (latency-bound otherwise)
+    if (gy < 1) gy = 1;
+    if (gy > (M + 7) / 8) gy = (M + 7) / 8;
+    int rows = (M + gy - 1) / gy;
+    rows = (rows + 7) / 8 * 8;
+    gy = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(gx, gy), dim3(256), 0, s, x, ldx, M, N, o0, o1, o2, n_each, rows);
 }
 
 // column sums: workgroup = 64 columns x a row range; thread (cc = t&7 -> 8 columns, rl = t>>3 -> row lane of 32)
@@ -254,6 +298,15 @@ extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
         case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
         default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
     }
+    if (a->workspace && (a->dgamma || a->dbeta || a->dbias))
+        launch_colsum_f32(a->workspace, 3L * a->D, grid, 3 * a->D, a->dgamma, a->dbeta, a->dbias, a->D, (hipStream_t)stream);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_colsum_f32(const wj_colsum_args* a, void* stream) {
+    if (!a || !a->x || !a->out || a->M <= 0 || a->N <= 0 || (a->N & 3) || (a->ldx & 3)) return WJ_ERR_ARG;
+    launch_colsum_f32((const float*)a->x, a->ldx, a->M, a->N, a->out, nullptr, nullptr, a->N, (hipStream_t)stream);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

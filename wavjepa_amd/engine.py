@@ -271,6 +271,8 @@ class JepaEngine:
                 dsb=torch.empty(m, d, dtype=bf, device=dev), dh=torch.empty(m, 4 * d, dtype=bf, device=dev),
                 dx1=torch.empty(m, d, dtype=f32, device=dev), do=torch.empty(m, d, dtype=bf, device=dev),
                 dqkv=torch.empty(m, 3 * d, dtype=bf, device=dev))
+        # scratch for two-stage parameter-gradient reductions (LayerNorm: [1536][3][D]; attention in_proj bias: [B][3D])
+        self.red_ws = torch.empty(max(1536 * 3 * max(c.d_enc, c.d_dec, C), N * G * 3 * c.d_dec, N * 3 * c.d_enc), dtype=f32, device=dev)
         self.dpreds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
         self.d_cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)
         self.d_ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)
@@ -299,16 +301,18 @@ class JepaEngine:
                    M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict) -> None:
         """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer."""
         ds, dsb, dh, dx1, do, dqkv = bw["ds"], bw["dsb"], bw["dh"], bw["dx1"], bw["do"], bw["dqkv"]
-        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2)
+        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2,
+                          workspace=self.red_ws)
         self._wgrad(dsb, a.g, w.gw2, D, 4 * D, M)
         ops.gemm(dsb, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
                  colsum=w.gb1)           # linear1.bias gradient = column sums of dh, fused into the producing epilogue
         self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
         ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
-        ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo)
+        ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
+                          workspace=self.red_ws)
         self._wgrad(dsb, a.o, w.gwo, D, D, M)
         ops.gemm(dsb, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
-        ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv)
+        ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
         self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, M)
         ops.gemm(dqkv, w.wqkv, dx_out, M=M, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
 
@@ -412,7 +416,7 @@ class JepaEngine:
                  b_trans=1, epilogue=ops.EPI_ADD_F32)
         last = self.dec_acts[-1]
         ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Mp, D=Dd, ds_f32=bw["dy"],
-                          dgamma=f.gptr("decoder.norm.weight"), dbeta=f.gptr("decoder.norm.bias"))
+                          dgamma=f.gptr("decoder.norm.weight"), dbeta=f.gptr("decoder.norm.bias"), workspace=self.red_ws)
         dy = bw["dy"]
         for i in range(c.l_dec - 1, -1, -1):
             x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
@@ -429,7 +433,7 @@ class JepaEngine:
         ops.unmask_rows_f32(self.d_ctx_in, plan.inv, bw["dx1"], M=M, D=De)
         last = self.enc_acts[-1]
         ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("encoder.norm.weight"), self.enc_fm, self.enc_fr, M=M, D=De, ds_f32=bw["dy"],
-                          dgamma=f.gptr("encoder.norm.weight"), dbeta=f.gptr("encoder.norm.bias"))
+                          dgamma=f.gptr("encoder.norm.weight"), dbeta=f.gptr("encoder.norm.bias"), workspace=self.red_ws)
         dy = bw["dy"]
         for i in range(c.l_enc - 1, -1, -1):
             x_in, xb_in = (self.lf, self.lf_b) if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)

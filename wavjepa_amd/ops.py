@@ -72,7 +72,7 @@ def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, 
 
 def pick_split_k(M: int, N: int, K: int) -> int:
     """Split-K factor for the wgrad GEMM: fill the 256 CUs (tile 256 x 256 -> 1 workgroup/CU, 256 x 128 -> 2)."""
-    bn = 256 if N % 256 == 0 else 128           # mirrors pick_bn() in csrc/gemm.hip for the ATOMIC (wgrad) epilogue
+    bn = 256 if N % 256 == 0 else 128           # mirrors pick_variant() in csrc/gemm.hip for the ATOMIC (wgrad) epilogue
     tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
     target = 256 if bn == 256 else 512
     s = max(1, (target + tiles // 2) // max(1, tiles))
@@ -91,15 +91,19 @@ def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, 
 def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
                   ds_f32: Ptr = None, ds_bf16: Ptr = None, dgamma: Ptr = None, dbeta: Ptr = None, dbias: Ptr = None,
                   x_is_bf16: bool = False, in_seg: int = 0, in_valid: int = 0, out_seg: int = 0, out_valid: int = 0,
-                  stream: Optional[int] = None) -> None:
+                  workspace: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_layernorm_bwd", "wj_ln_bwd_args", stream, dy=_p(dy), dy2=_p(dy2), x=_p(x), r=_p(r), gamma=_p(gamma),
          mean=_p(mean), rstd=_p(rstd), ds_f32=_p(ds_f32), ds_bf16=_p(ds_bf16), dgamma=_p(dgamma), dbeta=_p(dbeta),
-         dbias=_p(dbias), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, out_seg=out_seg,
+         dbias=_p(dbias), workspace=_p(workspace), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, out_seg=out_seg,
          out_valid=out_valid)
 
 
 def colsum_bf16(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[int] = None) -> None:
     _run("wj_colsum_bf16", "wj_colsum_args", stream, x=_p(x), out=_p(out), ldx=ldx, M=M, N=N)
+
+
+def colsum_f32(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[int] = None) -> None:
+    _run("wj_colsum_f32", "wj_colsum_args", stream, x=_p(x), out=_p(out), ldx=ldx, M=M, N=N)
 
 
 # ---------------------------------------------------------------------------------------------------------- attention
@@ -110,9 +114,9 @@ def attn_fwd(qkv: Ptr, out: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: P
 
 
 def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None,
-             mask_group: int = 1, dbias: Ptr = None, stream: Optional[int] = None) -> None:
+             mask_group: int = 1, dbias: Ptr = None, dbias_ws: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_attn_bwd", "wj_attn_bwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), out=_p(out), dout=_p(dout),
-         lse=_p(lse), dqkv=_p(dqkv), dbias=_p(dbias), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
+         lse=_p(lse), dqkv=_p(dqkv), dbias=_p(dbias), dbias_ws=_p(dbias_ws), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
 
 
 # ---------------------------------------------------------------------------------------------------------- conv front-end
