@@ -57,6 +57,9 @@ def gemm_kernel_name(f) -> str:
 def profile_one_step(runner, source, step_idx: int):
     """Run one extra step with every C-ABI call bracketed by HIP events; returns per-kernel-class totals."""
     from wavjepa_amd import ops
+    eng = runner.model._engine
+    side = eng.use_side
+    eng.use_side = False            # serialise the side-stream work so that every kernel is timed alone
     ops.PROFILE = []
     try:
         runner.step(source.next_batch(), step_idx)
@@ -64,6 +67,7 @@ def profile_one_step(runner, source, step_idx: int):
         recs = ops.PROFILE
     finally:
         ops.PROFILE = None
+        eng.use_side = side
     classes = {}
     for fn, f, e0, e1 in recs:
         ms = e0.elapsed_time(e1)

@@ -139,6 +139,12 @@ class JepaEngine:
         assert all(c == self.C for c, _, _ in cfg.conv_spec), "all conv layers must have the same width"
         assert cfg.d_enc % cfg.h_enc == 0 and cfg.d_dec % cfg.h_dec == 0
         self.N = 0
+        # second HIP stream: work that is off the critical path (teacher forward; all weight-gradient GEMMs of the
+        # backward) runs beside the main chain and fills the tails / write bursts of its kernels (WJ_SIDE_STREAM=0: off)
+        import os as _os
+        self.use_side = _os.environ.get("WJ_SIDE_STREAM", "1") != "0"
+        self.side = torch.cuda.Stream(device=self.dev)
+        self._ev = [torch.cuda.Event() for _ in range(8)]
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
         self._bind_params()
         self._conv_w: Dict[str, torch.Tensor] = {}
@@ -266,11 +272,15 @@ class JepaEngine:
         # backward scratch, one set per stack width
         self.bw = {}
         for tag, (m, d) in dict(enc=(M, c.d_enc), dec=(Mp, c.d_dec)).items():
+            # buffers read by the side-stream wgrad GEMMs exist twice (layer parity), so the main chain may run one layer ahead
             self.bw[tag] = dict(
                 dy=torch.empty(m, d, dtype=f32, device=dev), ds=torch.empty(m, d, dtype=f32, device=dev),
-                dsb=torch.empty(m, d, dtype=bf, device=dev), dh=torch.empty(m, 4 * d, dtype=bf, device=dev),
                 dx1=torch.empty(m, d, dtype=f32, device=dev), do=torch.empty(m, d, dtype=bf, device=dev),
-                dqkv=torch.empty(m, 3 * d, dtype=bf, device=dev))
+                dsb2=[torch.empty(m, d, dtype=bf, device=dev) for _ in range(2)],
+                dsb1=[torch.empty(m, d, dtype=bf, device=dev) for _ in range(2)],
+                dh=[torch.empty(m, 4 * d, dtype=bf, device=dev) for _ in range(2)],
+                dqkv=[torch.empty(m, 3 * d, dtype=bf, device=dev) for _ in range(2)],
+                done=[torch.cuda.Event() for _ in range(2)], used=[False, False])
         # scratch for two-stage parameter-gradient reductions (LayerNorm: [1536][3][D]; attention in_proj bias: [B][3D])
         self.red_ws = torch.empty(max(1536 * 3 * max(c.d_enc, c.d_dec, C), N * G * 3 * c.d_dec, N * 3 * c.d_enc), dtype=f32, device=dev)
         self.dpreds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
@@ -297,23 +307,55 @@ class JepaEngine:
         ops.gemm(dY, X, gW, M=n_out, N=k_in, K=m_tok, lda=n_out, ldb=k_in, ldc=k_in, a_trans=1, b_trans=1,
                  epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(n_out, k_in, m_tok))
 
+    def _on_side(self, fn) -> None:
+        """Run `fn` (kernel launches) on the side stream after everything enqueued so far on the main stream."""
+        if not self.use_side:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def _join_side(self) -> None:
+        if self.use_side:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream().wait_event(ev)
+
     def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dx_out: torch.Tensor,
-                   M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict) -> None:
-        """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer."""
-        ds, dsb, dh, dx1, do, dqkv = bw["ds"], bw["dsb"], bw["dh"], bw["dx1"], bw["do"], bw["dqkv"]
-        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2,
+                   M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int) -> None:
+        """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer.
+        The four weight-gradient GEMMs only need (dY, X) and nothing downstream needs them before the optimiser: they run on
+        the side stream while the main stream continues the dgrad chain."""
+        ds, dx1, do = bw["ds"], bw["dx1"], bw["do"]
+        dsb2, dsb1, dh, dqkv = bw["dsb2"][parity], bw["dsb1"][parity], bw["dh"][parity], bw["dqkv"][parity]
+        if self.use_side and bw["used"][parity]:
+            torch.cuda.current_stream().wait_event(bw["done"][parity])   # side stream finished reading this parity's buffers
+        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb2, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2,
                           workspace=self.red_ws)
-        self._wgrad(dsb, a.g, w.gw2, D, 4 * D, M)
-        ops.gemm(dsb, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
+        ops.gemm(dsb2, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
                  colsum=w.gb1)           # linear1.bias gradient = column sums of dh, fused into the producing epilogue
-        self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
+
+        def wgrad_mlp():
+            self._wgrad(dsb2, a.g, w.gw2, D, 4 * D, M)
+            self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
+        self._on_side(wgrad_mlp)
         ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
-        ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
+        ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb1, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
                           workspace=self.red_ws)
-        self._wgrad(dsb, a.o, w.gwo, D, D, M)
-        ops.gemm(dsb, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+        ops.gemm(dsb1, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
         ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
-        self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, M)
+
+        def wgrad_attn():
+            self._wgrad(dsb1, a.o, w.gwo, D, D, M)
+            self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, M)
+            if self.use_side:
+                bw["done"][parity].record(self.side)
+                bw["used"][parity] = True
+        self._on_side(wgrad_attn)
         ops.gemm(dqkv, w.wqkv, dx_out, M=M, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
 
     # ------------------------------------------------------------------------------------------------ front-end
@@ -351,6 +393,9 @@ class JepaEngine:
         M, Mp, T, G = self.M, self.Mp, self.T, c.groups
         De, Dd = c.d_enc, c.d_dec
         self._frontend(audio)
+        # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
+        # independent of the student / predictor chain below, so it runs beside it on the side stream
+        self._on_side(self._teacher_targets)
         # student encoder (keys restricted to the context)
         x, xb = self.lf, self.lf_b
         for w, a in zip(self.enc_layers, self.enc_acts):
@@ -373,8 +418,7 @@ class JepaEngine:
                           y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr)
         ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Mp, N=De, K=Dd, lda=Dd, ldb=Dd,
                  ldc=De, bias=f.ptr32("decoder_to_encoder_mapper.bias"))
-        # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of last k layers
-        self._teacher_targets()
+        self._join_side()               # teacher targets (side stream) are needed by the loss
         ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=N, G=G, T=T, D=De)
 
     def _teacher_targets(self) -> None:
@@ -420,7 +464,7 @@ class JepaEngine:
         dy = bw["dy"]
         for i in range(c.l_dec - 1, -1, -1):
             x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
-            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Mp, Dd, c.h_dec, N * G, plan.vis_u8, bw)
+            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Mp, Dd, c.h_dec, N * G, plan.vis_u8, bw, i & 1)
         n_ctx = plan.n_ctx
         ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G)
         # encoder_to_decoder_mapper (rows = gathered context tokens)
@@ -428,6 +472,8 @@ class JepaEngine:
         self._wgrad(self.d_cf, self.ctx_in, f.gptr("encoder_to_decoder_mapper.weight"), Dd, De, n_ctx)
         ops.gemm(self.d_cf, f.ptr16("encoder_to_decoder_mapper.weight"), self.d_ctx_in, M=n_ctx, N=De, K=Dd, lda=Dd, ldb=De,
                  ldc=De, b_trans=1)
+        if on_grads_ready is not None:
+            self._join_side()
         ready("dec")
         bw = self.bw["enc"]
         ops.unmask_rows_f32(self.d_ctx_in, plan.inv, bw["dx1"], M=M, D=De)
@@ -437,7 +483,9 @@ class JepaEngine:
         dy = bw["dy"]
         for i in range(c.l_enc - 1, -1, -1):
             x_in, xb_in = (self.lf, self.lf_b) if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
-            self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, M, De, c.h_enc, N, plan.ctx_u8, bw)
+            self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, M, De, c.h_enc, N, plan.ctx_u8, bw, i & 1)
+            if on_grads_ready is not None:
+                self._join_side()        # this layer's weight gradients (side stream) are part of the section
             ready(f"enc:{i}")
         # dy = d(local_features) fp32.  The teacher branch is detached (jepa.py:408).
         ops.cast_f32_to_bf16(dy, self.d_lf_b, M * De)
@@ -477,6 +525,9 @@ class JepaEngine:
                       f.gptr("extract_audio.cnn.0.0.weight"), f.gptr("extract_audio.cnn.0.2.weight"),
                       f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws, N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0,
                       stride=s0, L_out=self.L[0], P=self.P[0])
+        self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
+        for tag in ("enc", "dec"):
+            self.bw[tag]["used"] = [False, False]
         ready("front")
 
     # ------------------------------------------------------------------------------------------------ EMA / inference
