@@ -39,8 +39,8 @@ int wj_struct_size(const char* name);
  * -----------------------------------------------------------------------------------------------------------*/
 enum {
     WJ_EPI_BF16 = 0,          /* C(bf16)  = acc (+ bias[n])                                                  */
-    WJ_EPI_BIAS_GELU2 = 1,    /* C(bf16)  = h = acc + bias ;  C2(bf16) = gelu(h)   (linear1 + nn.GELU)         */
-    WJ_EPI_MUL_GELU_GRAD = 2, /* C(bf16)  = bf16(acc) * gelu'(aux(bf16))           (backward through GELU)     */
+    WJ_EPI_BIAS_GELU2 = 1,    /* h = bf16(acc + bias);  C(bf16) = gelu'(h) ;  C2(bf16) = gelu(h)   (linear1 + nn.GELU)  */
+    WJ_EPI_MUL_GELU_GRAD = 2, /* C(bf16)  = bf16(acc) * aux(bf16), aux = the gelu'(h) saved by EPI 1 (backward through GELU) */
     WJ_EPI_ADD_F32 = 3,       /* C(f32)   = acc (+ aux(f32))                       (dgrad + residual-stream)   */
     WJ_EPI_ATOMIC_F32 = 4,    /* C(f32)  += alpha * acc   (atomic; split_k >= 1)   (wgrad into the grad buffer) */
     WJ_EPI_CONV_GELU = 5      /* C(bf16)  = pre = bf16(acc); C2(bf16) = gelu(pre); rows (m % seg_rows) >= seg_valid -> 0 */

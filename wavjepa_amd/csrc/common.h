@@ -67,6 +67,14 @@ __device__ __forceinline__ float gelu_f(float x) {
     erf_parts(x, ea, e);
     return 0.5f * x * (1.0f + copysignf(ea, x));
 }
+// gelu(x) and gelu'(x) from one erf / one exp
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& gp) {
+    float ea, e;
+    erf_parts(x, ea, e);
+    const float cdf = 0.5f * (1.0f + copysignf(ea, x));
+    g = x * cdf;
+    gp = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float ea, e;
     erf_parts(x, ea, e);

@@ -401,15 +401,22 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                         for (int x = 0; x < 8; ++x) csum[x] += bf2f(v[x]);
                     }
                 } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
-                    bf16x8 gl;
+                    // h = v (bf16).  Stored: C = gelu'(h) (all the backward needs of h: one multiply there, no erf/exp),
+                    // C2 = gelu(h); both from the same erf and exp.
+                    bf16x8 gl, gp;
 #pragma unroll
-                    for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
-                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
+                    for (int x = 0; x < 8; ++x) {
+                        float g0, g1;
+                        gelu_both_f(bf2f(v[x]), g0, g1);
+                        gl[x] = f2bf(g0);
+                        gp[x] = f2bf(g1);
+                    }
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gp;
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
                 } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
                     bf16x8 o;
 #pragma unroll
-                    for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * gelu_grad_f(bf2f(hx[ps][x])));
+                    for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * bf2f(hx[ps][x]));   // aux = gelu'(h) saved by the forward
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
                     if (e.colsum) {
 #pragma unroll

@@ -134,12 +134,16 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n, f
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[r] = f2bf(gelu_f(bf2f(o[r])));
             *reinterpret_cast<bf16x4*>((bf16_t*)e.C2 + off) = g;
+            bf16x4 gp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[r] = f2bf(gelu_grad_f(bf2f(o[r])));
+            *reinterpret_cast<bf16x4*>((bf16_t*)e.C + off) = gp;
         }
     } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
         const bf16x4 h = *reinterpret_cast<const bf16x4*>((const bf16_t*)e.aux + off);
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(f2bf(acc[r])) * gelu_grad_f(bf2f(h[r])));
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(f2bf(acc[r])) * bf2f(h[r]));
         *reinterpret_cast<bf16x4*>((bf16_t*)e.C + off) = o;
     } else if constexpr (EPI == WJ_EPI_ADD_F32) {
         f32x4 o = acc;

@@ -206,7 +206,7 @@ class JepaEngine:
             a.r1 = torch.empty(M, dtype=f32, device=dev)
             a.x1 = torch.empty(M, D, dtype=f32, device=dev)
             a.x1b = torch.empty(M, D, dtype=bf, device=dev)
-            a.h = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            a.h = torch.empty(M, 4 * D, dtype=bf, device=dev)        # holds gelu'(linear1 output), see EPI_BIAS_GELU2
             a.g = torch.empty(M, 4 * D, dtype=bf, device=dev)
             a.f = torch.empty(M, D, dtype=bf, device=dev)
             a.m2 = torch.empty(M, dtype=f32, device=dev)
