@@ -160,7 +160,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -175,7 +175,7 @@ def main():
         step_idx += 1
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -231,7 +231,7 @@ def main():
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_classes.json"), "w") as fh:
                 json.dump({k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None) for k, v in top}, fh, indent=1)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

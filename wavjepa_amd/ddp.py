@@ -56,10 +56,13 @@ class FlatGradAllReducer:
         self.handles: List = []
         self._ranges: Optional[Dict[str, List[Tuple[int, int]]]] = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # a process group of size 1 (torch.distributed.run --nproc-per-node 1) still runs every collective: the single-GPU
+        # box exercises exactly the code path the 8-GPU launch uses
+        self.active = dist.is_initialized()
 
     def broadcast_parameters(self) -> None:
         """Rank 0's student, teacher and optimiser-visible state to everyone (DDP constructor broadcast)."""
-        if self.world == 1:
+        if not self.active:
             return
         self.module._ensure_engine()
         flat = self.module._flat
@@ -69,7 +72,7 @@ class FlatGradAllReducer:
         self.module._teacher_bf16_fresh = False
 
     def hook(self, tag: str) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         flat = self.module._flat
         if self._ranges is None:

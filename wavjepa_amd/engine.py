@@ -445,7 +445,14 @@ class JepaEngine:
         `on_grads_ready(tag)` is called (host side, stream-ordered) as sections of the flat gradient buffer become
         final: "dec" (predictor + both mappers), "enc:<i>" after encoder layer i, "front" at the end -- the hook the
         data-parallel wrapper uses to launch bucketed RCCL all-reduces that overlap the rest of the backward."""
-        ready = on_grads_ready if on_grads_ready is not None else (lambda tag: None)
+        if on_grads_ready is None:
+            ready = lambda tag: None
+        elif self.use_side:
+            # a section is final once BOTH streams are past this point: issue the hook (the bucket's all-reduce) from the
+            # side stream after it has waited for the main stream, so that the main dgrad chain never stalls on it
+            ready = lambda tag: self._on_side(lambda: on_grads_ready(tag))
+        else:
+            ready = on_grads_ready
         c, f, plan = self.cfg, self.flat, self.plan
         N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, c.groups, self.C
         De, Dd = c.d_enc, c.d_dec
@@ -472,8 +479,6 @@ class JepaEngine:
         self._wgrad(self.d_cf, self.ctx_in, f.gptr("encoder_to_decoder_mapper.weight"), Dd, De, n_ctx)
         ops.gemm(self.d_cf, f.ptr16("encoder_to_decoder_mapper.weight"), self.d_ctx_in, M=n_ctx, N=De, K=Dd, lda=Dd, ldb=De,
                  ldc=De, b_trans=1)
-        if on_grads_ready is not None:
-            self._join_side()
         ready("dec")
         bw = self.bw["enc"]
         ops.unmask_rows_f32(self.d_ctx_in, plan.inv, bw["dx1"], M=M, D=De)
@@ -484,8 +489,6 @@ class JepaEngine:
         for i in range(c.l_enc - 1, -1, -1):
             x_in, xb_in = (self.lf, self.lf_b) if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
             self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, M, De, c.h_enc, N, plan.ctx_u8, bw, i & 1)
-            if on_grads_ready is not None:
-                self._join_side()        # this layer's weight gradients (side stream) are part of the section
             ready(f"enc:{i}")
         # dy = d(local_features) fp32.  The teacher branch is detached (jepa.py:408).
         ops.cast_f32_to_bf16(dy, self.d_lf_b, M * De)
@@ -528,7 +531,8 @@ class JepaEngine:
         self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
         for tag in ("enc", "dec"):
             self.bw[tag]["used"] = [False, False]
-        ready("front")
+        if on_grads_ready is not None:
+            on_grads_ready("front")
 
     # ------------------------------------------------------------------------------------------------ EMA / inference
     def ema_step(self, r: float) -> None:

@@ -19,7 +19,8 @@ def init_distributed() -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # started by torch.distributed.run (any world size)
+    if launched and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
@@ -37,7 +38,7 @@ class StepRunner:
         model._ensure_engine()
         self.reducer = FlatGradAllReducer(model, enc_chunk=enc_chunk)
         self.reducer.broadcast_parameters()
-        model._grads_ready_hook = self.reducer.hook
+        model._grads_ready_hook = self.reducer.hook if self.reducer.active else None
         oc = model.configure_optimizers()
         self.optimizer = oc["optimizer"]
         self.scheduler = oc["lr_scheduler"]["scheduler"]
