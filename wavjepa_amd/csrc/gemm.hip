@@ -170,7 +170,10 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = wg / split_k, ksl = wg - tile * split_k;
+    // split-K work order: K-slice major, tile minor -> the tiles that stream the same K-slice of A / B are neighbours on one
+    // XCD and share it through L2 (tile-major order fetched ~3x the algorithmic bytes: profiles/r01_pmc_traffic.json)
+    const int ntiles = gridDim.x / split_k;
+    const int ksl = wg / ntiles, tile = wg - ksl * ntiles;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = ksl * k_per_split;
