@@ -190,9 +190,11 @@ def main():
     note(f"timed region done: {elapsed / args.steps * 1000:.1f} ms/step")
     roofline = None
     classes = {}
+    executed_gflop = None
     if not args.no_profile:
         classes = profile_one_step(runner, source, step_idx)
         gemms = {k: v for k, v in classes.items() if v["flops"] > 0}
+        executed_gflop = sum(v["flops"] for v in gemms.values()) / 1e9      # GEMM flops one step actually executes
         if gemms:
             name, c = max(gemms.items(), key=lambda kv: kv[1]["ms"])
             all_ms = sum(v["ms"] for v in gemms.values())
@@ -215,8 +217,13 @@ def main():
             "config": {"workload": "WavJEPA-base JEPA pre-training step, 2.01 s @16 kHz white-noise clips (32159 samples -> 200 tokens), "
                                    f"{args.clips_per_gpu} clips per GPU (32 sources x 8 crops), AudioSet masker, random-init weights",
                        "global_batch": args.clips_per_gpu * world, "seq_len": 200, "parallelism": f"dp{world}",
-                       "step_gflop_per_clip": STEP_GFLOP_PER_CLIP},
-            "model_tflops_per_gpu": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1),
+                       # student / predictor run on their visible tokens only unless WJ_RAGGED=0 (same loss and gradients:
+                       # the dropped rows are key-masked and carry zero loss weight on the reference)
+                       "token_execution": "ragged" if model._engine.ragged else "dense",
+                       "step_gflop_per_clip_dense": STEP_GFLOP_PER_CLIP,
+                       "step_gemm_gflop_per_clip_executed": None if executed_gflop is None else round(executed_gflop / args.clips_per_gpu, 1)},
+            # executed GEMM flops (instrumented step) over the measured step time; NOT the dense-shape flop count
+            "model_tflops_per_gpu": None if executed_gflop is None else round(executed_gflop / (elapsed / args.steps) / 1000, 1),
             "final_loss": round(loss, 5),
             "roofline": roofline,
         }

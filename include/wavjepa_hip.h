@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 1
+#define WJ_ABI_VERSION 2
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -132,10 +132,15 @@ int wj_colsum_f32(const wj_colsum_args*, void* stream);
  * teacher (jepa.py:256-258, no mask).   qkv: bf16 [B][T][3*H*hd] packed q|k|v;  key_mask: u8 [B][T], nonzero =
  * key NOT attended, or NULL;  out: bf16 [B][T][H*hd];  lse: f32 [B][H][T] (log-sum-exp of scaled scores).
  * hd in {32, 64};  T <= 224.
+ * Ragged form (seq_off != NULL): the B sequences are PACKED back to back, sequence b = rows [seq_off[b], seq_off[b+1])
+ * of qkv / out / dout / dqkv, every key attended (key_mask must be NULL), T = upper bound of the lengths, and
+ * lse: f32 [rows][H].  This is how the student / predictor run on their visible tokens only: a key-masked query row
+ * that nobody reads (jepa.py:399 keeps ~ctx_masks rows; the loss keeps target rows, jepa.py:356) is never computed.
  * -----------------------------------------------------------------------------------------------------------*/
 typedef struct {
     const void* qkv;
     const uint8_t* key_mask;
+    const int32_t* seq_off; /* optional int32 [B+1]: ragged form */
     void* out;
     float* lse;
     int32_t B, T, H, hd;
@@ -146,6 +151,7 @@ int wj_attn_fwd(const wj_attn_fwd_args*, void* stream);
 typedef struct {
     const void* qkv;
     const uint8_t* key_mask;
+    const int32_t* seq_off; /* optional int32 [B+1]: ragged form */
     const void* out;
     const void* dout; /* bf16 [B][T][H*hd] */
     const float* lse;
@@ -242,36 +248,45 @@ int wj_mask_gather_rows(const wj_gather_args*, void* stream);
 
 /* Predictor input (jepa.py:425-435):  for group g, row (b,t):
  *   tok = inv[b*T+t] >= 0 ? ctx_feats[inv[b*T+t]] : mask_token        (bf16)
- *   out_f32[(b*G+g)][t] = f32(tok) + pos[t];  out_bf16 = bf16(out_f32) */
+ *   out_f32[(b*G+g)][t] = f32(tok) + pos[t];  out_bf16 = bf16(out_f32)
+ * Ragged form (rows != NULL): only the n_rows listed rows are produced, packed: out[r] = the row above for the dense
+ * index rows[r] = (b*G+g)*T + t (the visible = context-or-target tokens of every (clip, group), ascending). */
 typedef struct {
     const void* ctx_feats;   /* bf16 [n_ctx][D] */
     const int32_t* inv;      /* [B*T]: position in ctx_feats or -1 */
     const float* mask_token; /* f32 [D] */
     const float* pos;        /* f32 [T][D] */
+    const int32_t* rows;     /* optional int32 [n_rows]: ragged form */
     float* out_f32;
     void* out_bf16;
     int32_t B, T, D, G;
+    int32_t n_rows;
 } wj_scatter_fill_args;
 int wj_mask_scatter_fill_pos(const wj_scatter_fill_args*, void* stream);
 
 /* Backward of the above: dtok[b*T+t] = sum_g d_in[(b*G+g)][t] (f32);  rows with inv >= 0 go to d_ctx_feats (bf16),
- * the others are summed into d_mask_token (f32, atomic). */
+ * the others are summed into d_mask_token (f32, atomic).
+ * Ragged form (rowmap != NULL): d_in is packed; rowmap[(b*G+g)*T + t] = its row for that token or -1 (not visible:
+ * contributes nothing). */
 typedef struct {
     const float* d_in;
     const int32_t* inv;
+    const int32_t* rowmap;   /* optional int32 [B*G*T]: ragged form */
     void* d_ctx_feats;
     float* d_mask_token;
     int32_t B, T, D, G;
 } wj_scatter_fill_bwd_args;
 int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args*, void* stream);
 
-/* dst_f32[m][:] = inv[m] >= 0 ? f32(src_bf16[inv[m]][:]) : 0   for all M rows (dgrad of the gather: the gradient
- * w.r.t. the student encoder output is zero on non-context rows, jepa.py:399). */
+/* dst[m][:] = inv[m] >= 0 ? src[inv[m]][:] : 0   for all M rows (dgrad of the gather: the gradient w.r.t. the
+ * student encoder output / the local features is zero on non-context rows, jepa.py:399).  src is bf16 (or f32 when
+ * src_is_f32), dst is f32 (or bf16 when dst_is_bf16); inv == NULL is the identity (a plain widening / narrowing copy). */
 typedef struct {
     const void* src;
     const int32_t* inv;
-    float* dst;
+    void* dst;
     int32_t M, D;
+    int32_t src_is_f32, dst_is_bf16;
 } wj_unmask_rows_args;
 int wj_unmask_rows_f32(const wj_unmask_rows_args*, void* stream);
 
@@ -292,16 +307,20 @@ int wj_instnorm_accumulate(const wj_instnorm_args*, void* stream);
 /* Masked MSE (jepa.py:335-362).  preds bf16 [B*G][T][D], targets f32 [B][T][D], tgt u8 [B][G][T].
  *   loss[0] = sum_{tgt} mean_d (p - y)^2 / (count + 1e-8);  loss[1] = count.
  *   If dpreds != NULL also writes dpreds (bf16) = tgt ? 2 (p - y) / (D (count + 1e-8)) * gscale : 0.
- * workspace: f32 [2 + B*G*T]. */
+ * workspace: f32 [2 + B*G*T].
+ * Ragged form (rows != NULL): preds / dpreds hold only the n_rows packed rows, row r standing for the dense index
+ * rows[r] = (b*G+g)*T + t; tgt and targets stay dense. */
 typedef struct {
     const void* preds;
     const float* targets;
     const uint8_t* tgt;
+    const int32_t* rows;     /* optional int32 [n_rows]: ragged form */
     float* loss;
     void* dpreds;
     float* workspace;
     const float* gscale_ptr; /* optional DEVICE scalar multiplied into gscale (the upstream d(loss), no host sync) */
     int32_t B, G, T, D;
+    int32_t n_rows;
     float gscale;
 } wj_mse_args;
 int wj_masked_mse(const wj_mse_args*, void* stream);

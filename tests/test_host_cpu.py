@@ -29,7 +29,7 @@ def small_model(**kw):
 def test_abi_library_exports_every_declared_symbol():
     from wavjepa_amd import _abi
     lib = _abi.load()
-    assert lib.wj_abi_version() == 1
+    assert lib.wj_abi_version() == 2
     assert len(_abi.FUNCTIONS) >= 25
     for fn in _abi.FUNCTIONS:
         assert hasattr(lib, fn), fn
@@ -195,6 +195,16 @@ def test_conv_geometry_and_mask_plan():
     plan = make_mask_plan(ctx, tgt, tgt, torch.device("cpu"))
     assert plan.n_ctx == 4 and plan.keep.tolist() == [1, 2, 4, 7] and plan.inv.tolist() == [-1, 0, 1, -1, 2, -1, -1, 3]
     assert plan.vis_u8.shape == (4, 4)
+    # ragged index lists: context rows per clip; visible predictor rows per (clip, group), packed in (b, g, t) order
+    tgt[0, 0, 0] = tgt[0, 1, 3] = tgt[1, 1, 1] = True
+    vis = ~((~ctx)[:, None] | tgt)
+    plan = make_mask_plan(ctx, tgt, vis, torch.device("cpu"))
+    assert plan.ragged_ok and plan.enc_off.tolist() == [0, 2, 4] and plan.max_enc == 2
+    assert plan.dec_rows.tolist() == [0, 1, 2, 5, 6, 7, 8, 11, 12, 13, 15] and plan.n_dec == 11
+    assert plan.dec_off.tolist() == [0, 3, 6, 8, 11] and plan.max_dec == 3
+    assert plan.dec_map.tolist() == [0, 1, 2, -1, -1, 3, 4, 5, 6, -1, -1, 7, 8, 9, -1, 10]
+    vis[0, 0, 0] = True                                            # a key-masked target: not expressible in ragged form
+    assert not make_mask_plan(ctx, tgt, vis, torch.device("cpu")).ragged_ok
 
 
 def test_config_loader_and_factories():

@@ -69,20 +69,32 @@ def group_of(name):
     return "other"
 
 
-@pytest.mark.parametrize("cfg_name,n", [("small", 4), ("base", 2)])
-def test_forward_backward_parity(golden_dir, cfg_name, n):
+@pytest.mark.parametrize("cfg_name,n,ragged", [("small", 4, True), ("small", 4, False), ("base", 2, True), ("base", 2, False)])
+def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
+    """ragged = visible-token execution (the default); dense = the reference's key-masked full-length shapes.  Both must
+    give the oracle's loss, outputs and gradients."""
     cfg = SMALL if cfg_name == "small" else BASE
     m, P = build(cfg)
+    m._ensure_engine().ragged = ragged
     ctx, tgt, vis = masks(golden_dir, n)
     audio = torch.from_numpy(synth.synth_audio(n, 1, 32159, seed=3)).to(torch.bfloat16).to(dev())
     out = m(audio, ctx, tgt, vis)
+    assert m._engine.ragged_step == ragged
     names = J.trainable_names(P)
     for k in names:
         P[k].requires_grad_(True)
     ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(cfg))
     ref32 = J.jepa_forward({k: v.detach() for k, v in P.items()}, audio.float(), ctx.to(dev()), tgt.to(dev()), vis.to(dev()),
                            mode="fp32", **oracle_kw(cfg))
-    report = {k: rel(out[k].float(), ref[k].float()) for k in ("local_features", "contextual_features", "preds", "targets")}
+    report = {k: rel(out[k].float(), ref[k].float()) for k in ("local_features", "contextual_features", "targets")}
+    seen = (~vis).reshape(-1, vis.shape[-1]).to(dev())            # predictor rows that exist on a ragged step
+    assert out["preds"].shape == ref["preds"].shape
+    report["preds"] = rel(out["preds"][seen].float(), ref["preds"][seen].float())
+    if ragged:
+        assert float(out["preds"][~seen].float().abs().max()) == 0.0
+    else:
+        report["preds_all"] = rel(out["preds"].float(), ref["preds"].float())
+        assert report["preds_all"] < 2e-2
     lo, lr_, l32 = float(out["loss"]), float(ref["loss"]), float(ref32["loss"])
     print(cfg_name, "rel errors vs oracle bf16:", report, "loss hip/oracle-bf16/oracle-fp32:", lo, lr_, l32)
     assert out["local_features"].dtype == torch.float32 and out["preds"].dtype == torch.bfloat16
@@ -115,9 +127,53 @@ def test_mask_gather_bit_exact_and_shapes(golden_dir):
         m(audio, ctx, tgt, vis)
     eng = m._engine
     n_ctx = int((~ctx).sum())
-    assert eng.plan.n_ctx == n_ctx
-    want = eng.enc_out_b.view(3, 200, -1)[(~ctx).to(dev())]
-    assert torch.equal(eng.ctx_in[:n_ctx], want)                     # pure copy in (b, t) row-major order
+    assert eng.plan.n_ctx == n_ctx and eng.ragged_step
+    sel = (~ctx).to(dev())
+    # ragged step: the boolean-mask gather happens on the encoder INPUT (pure copies in (b, t) row-major order) ...
+    assert torch.equal(eng.enc_in_b[:n_ctx], eng.lf_b.view(3, 200, -1)[sel])
+    assert torch.equal(eng.enc_in[:n_ctx], eng.lf.view(3, 200, -1)[sel])
+    ctx_ragged = eng.ctx_in[:n_ctx].clone()
+    # ... dense step: on the encoder output, as the reference does (jepa.py:399)
+    eng.ragged = False
+    with torch.no_grad():
+        m(audio, ctx, tgt, vis)
+    assert not eng.ragged_step
+    want = eng.enc_out_b.view(3, 200, -1)[sel]
+    assert torch.equal(eng.ctx_in[:n_ctx], want)
+    assert rel(ctx_ragged.float(), want.float()) < 1e-2              # same rows either way (bf16 summation-order noise only)
+
+
+def test_ragged_equals_dense_step(golden_dir):
+    """Visible-token execution changes no result: loss and every parameter gradient agree with the dense key-masked step
+    to accumulation-order noise."""
+    ctx, tgt, vis = masks(golden_dir, 4)
+    audio = torch.from_numpy(synth.synth_audio(4, 1, 32159, seed=9)).to(torch.bfloat16).to(dev())
+    res = {}
+    for ragged in (True, False):
+        m, _ = build(SMALL)
+        m._ensure_engine().ragged = ragged
+        out = m(audio, ctx, tgt, vis)
+        out["loss"].backward()
+        res[ragged] = (float(out["loss"]), {k: p.grad.double().clone() for k, p in m.named_parameters() if p.grad is not None})
+    (l1, g1), (l0, g0) = res[True], res[False]
+    assert abs(l1 - l0) < 2e-4 * abs(l0), (l1, l0)
+    num = sum(float((g1[k] - g0[k]).pow(2).sum()) for k in g0)
+    den = sum(float(g0[k].pow(2).sum()) for k in g0)
+    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
+
+
+def test_target_outside_visible_set_falls_back_to_dense(golden_dir):
+    """If a target position is key-masked the predictor row must still be computed as a query: such a batch takes the
+    dense path (the reference maskers never produce it)."""
+    m, _ = build(SMALL)
+    ctx, tgt, vis = masks(golden_dir, 2)
+    vis = vis.clone()
+    b, g, t = [int(v[0]) for v in torch.nonzero(tgt, as_tuple=True)]
+    vis[b, g, t] = True
+    audio = torch.from_numpy(synth.synth_audio(2, 1, 32159, seed=5)).to(torch.bfloat16).to(dev())
+    with torch.no_grad():
+        m(audio, ctx, tgt, vis)
+    assert m._engine.ragged and not m._engine.ragged_step
 
 
 def test_training_trajectory_vs_oracle(golden_dir):

@@ -268,6 +268,54 @@ def test_attention_no_mask(ops):
     assert relerr(out.float(), ref) < 8e-3
 
 
+@pytest.mark.parametrize("B,T,H,hd", [(5, 200, 12, 64), (8, 200, 12, 32), (3, 40, 2, 32)])
+def test_attention_ragged_matches_key_masked(ops, B, T, H, hd):
+    """Ragged form (packed visible rows, every key attended) == the dense key-masked form on the visible rows, and both
+    == plain softmax attention over each sequence's visible tokens."""
+    D = H * hd
+    qkv = rnd(B, T, 3 * D, dtype=torch.bfloat16, seed=34)
+    g = torch.Generator().manual_seed(35)
+    mask = (torch.rand(B, T, generator=g) < torch.linspace(0.3, 0.9, B)[:, None])
+    mask[:, 3] = False
+    mask[0] = True
+    mask[0, 7] = False                                          # a one-token sequence
+    mask = mask.to(dev())
+    vis = ~mask
+    lens = vis.sum(1)
+    off = torch.zeros(B + 1, dtype=torch.int32, device=dev())
+    off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    n = int(off[-1])
+    Tmax = int(lens.max())
+    pk = qkv[vis].contiguous()                                  # [n, 3D] packed in (b, t) order
+    out_r = torch.empty(n, D, dtype=torch.bfloat16, device=dev())
+    lse_r = torch.empty(n, H, device=dev())
+    ops.attn_fwd(pk, out_r, B=B, T=Tmax, H=H, hd=hd, seq_off=off, lse=lse_r)
+    out_d = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev())
+    lse_d = torch.empty(B, H, T, device=dev())
+    ops.attn_fwd(qkv, out_d, B=B, T=T, H=H, hd=hd, key_mask=mask.to(torch.uint8).contiguous(), lse=lse_d)
+    x = qkv.float().requires_grad_(True)
+    ref, ref_lse = ref_attention(x, H, mask)
+    assert relerr(out_r.float(), ref[vis]) < 8e-3
+    assert relerr(out_r.float(), out_d[vis].float()) < 8e-3
+    assert maxerr(lse_r, ref_lse.permute(0, 2, 1)[vis]) < 2e-3
+    dout = torch.zeros(B, T, D, dtype=torch.bfloat16, device=dev())
+    dout[vis] = rnd(n, D, dtype=torch.bfloat16, seed=36)        # invisible query rows get no gradient (zero loss weight)
+    ref.backward(dout.float())
+    dq_r = torch.empty_like(pk)
+    dbias = torch.zeros(3 * D, device=dev())
+    ws = torch.empty(B, 3 * D, device=dev())
+    ops.attn_bwd(pk, out_r, dout[vis].contiguous(), lse_r, dq_r, B=B, T=Tmax, H=H, hd=hd, seq_off=off, dbias=dbias, dbias_ws=ws)
+    want = x.grad[vis]
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert relerr(dq_r.float()[..., sl], want[..., sl]) < 1.5e-2, name
+    assert relerr(dbias, dq_r.float().sum(0)) < 1e-4
+    # invisible rows of the dense formulation indeed carry no gradient: the ragged form loses nothing
+    assert float(x.grad[mask][..., D:].abs().max()) == 0.0
+    from wavjepa_amd._abi import WavJepaHipError
+    with pytest.raises(WavJepaHipError):                        # ragged form and key mask are mutually exclusive
+        ops.attn_fwd(pk, out_r, B=B, T=Tmax, H=H, hd=hd, seq_off=off, key_mask=mask.to(torch.uint8).contiguous())
+
+
 # ------------------------------------------------------------------------------------------------------------ conv0
 @pytest.mark.parametrize("N,C_in,L,C", [(2, 1, 32159, 512), (3, 1, 4000, 32), (2, 2, 4000, 64)])
 def test_conv0_fwd_bwd(ops, N, C_in, L, C):
@@ -376,6 +424,37 @@ def test_token_plumbing(ops):
     ref = torch.zeros(B, T, D, device=dev())
     ref[~ctx_mask] = feats.float()
     assert torch.equal(back.reshape(B, T, D), ref)
+    # dtype variants + identity
+    f32src = rnd(n, D, seed=67)
+    back16 = torch.empty(B * T, D, dtype=torch.bfloat16, device=dev())
+    ops.unmask_rows_f32(f32src, inv, back16, M=B * T, D=D, src_is_f32=True, dst_is_bf16=True)
+    ref = torch.zeros(B, T, D, device=dev())
+    ref[~ctx_mask] = f32src
+    assert torch.equal(back16.reshape(B, T, D), ref.to(torch.bfloat16))
+    wide = torch.empty(n, D, device=dev())
+    ops.unmask_rows_f32(feats, None, wide, M=n, D=D)
+    assert torch.equal(wide, feats.float())
+
+    # ragged predictor input / its backward: only the visible rows of every (clip, group), packed
+    tmask = (torch.rand(B, G, T, generator=g) < 0.3).to(dev()) & ctx_mask[:, None]
+    vis = (~ctx_mask)[:, None] | tmask                                      # context or this group's targets
+    rows = torch.nonzero(vis.reshape(-1)).squeeze(1).to(torch.int32)
+    nd = int(rows.numel())
+    r32 = torch.empty(nd, D, device=dev())
+    r16 = torch.empty(nd, D, dtype=torch.bfloat16, device=dev())
+    ops.mask_scatter_fill_pos(feats, inv, mtok, pos, B=B, T=T, D=D, G=G, out_f32=r32, out_bf16=r16, rows=rows, n_rows=nd)
+    assert torch.equal(r32, o32.reshape(-1, D)[rows.long()]) and torch.equal(r16, o16.reshape(-1, D)[rows.long()])
+    rowmap = torch.full((B * G * T,), -1, dtype=torch.int32, device=dev())
+    rowmap[rows.long()] = torch.arange(nd, dtype=torch.int32, device=dev())
+    d_pk = rnd(nd, D, seed=68)
+    d_dense = torch.zeros(B * G * T, D, device=dev())
+    d_dense[rows.long()] = d_pk
+    dfe2 = torch.zeros(n, D, dtype=torch.bfloat16, device=dev())
+    dmt2 = torch.zeros(D, device=dev())
+    ops.mask_scatter_fill_pos_bwd(d_pk, inv, dfe2, dmt2, B=B, T=T, D=D, G=G, rowmap=rowmap)
+    dsum = d_dense.reshape(B, G, T, D).sum(1)
+    assert relerr(dfe2.float(), dsum[~ctx_mask]) < 4e-3
+    assert relerr(dmt2, dsum[ctx_mask].sum(0)) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------------------ targets / loss
@@ -402,6 +481,16 @@ def test_instnorm_and_mse(ops):
     assert abs(float(loss[0]) - float(ref_loss)) < 1e-5 * float(ref_loss)
     assert float(loss[1]) == float(tmask.sum())
     assert relerr(dp.float(), pr.grad) < 4e-3
+    # ragged form: preds hold only listed rows (targets + some extra non-target rows)
+    seen = tmask | (torch.rand(B, G, T, generator=g) < 0.2).to(dev())
+    rows = torch.nonzero(seen.reshape(-1)).squeeze(1).to(torch.int32)
+    nd = int(rows.numel())
+    pk = preds.reshape(-1, D)[rows.long()].contiguous()
+    loss2 = torch.zeros(2, device=dev())
+    dp2 = torch.empty_like(pk)
+    ops.masked_mse(pk, tg, tmask.to(torch.uint8), loss2, ws, B=B, G=G, T=T, D=D, dpreds=dp2, gscale=1.0, rows=rows, n_rows=nd)
+    assert abs(float(loss2[0]) - float(loss[0])) < 1e-6 * float(loss[0]) and float(loss2[1]) == float(loss[1])
+    assert torch.equal(dp2, dp.reshape(-1, D)[rows.long()])
 
 
 # ------------------------------------------------------------------------------------------------------------ optimiser side

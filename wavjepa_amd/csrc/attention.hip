@@ -103,16 +103,22 @@ template <int HD>
 __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = a.T, H = a.H, D = H * HD;
+    const int H = a.H, D = H * HD;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    int T = a.T;
+    long row0 = (long)b * a.T;
+    if (a.seq_off) {                     // ragged: this sequence's rows in the packed buffers
+        row0 = a.seq_off[b];
+        T = min(a.seq_off[b + 1] - (int)row0, a.T);
+    }
     const int nkt = (T + 15) / 16, KP = ((T + 31) / 32) * 32, nch = KP / 32;
     char* kimg = smem;
     char* vimg = smem + KP * RS;
     float* madd = reinterpret_cast<float*>(smem + 2 * KP * RS);
 
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const long ld = 3L * D;
-    const bf16_t* base = (const bf16_t*)a.qkv + (long)b * T * ld + h * HD;
+    const bf16_t* base = (const bf16_t*)a.qkv + row0 * ld + h * HD;
     bf16x8 qf[KS];                       // this wave's first query tile: in flight while K / V are staged
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, wave * 16, T, ks, lane);
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
         }
         const int q = qt * 16 + i;
         if (q < T) {
-            bf16_t* op = (bf16_t*)a.out + ((long)b * T + q) * D + h * HD;
+            bf16_t* op = (bf16_t*)a.out + (row0 + q) * D + h * HD;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 ov;
@@ -184,7 +190,8 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
                 for (int r = 0; r < 4; ++r) ov[r] = f2bf(o[dt][r]);
                 *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) = ov;
             }
-            if (a.lse && g == 0) a.lse[((long)b * H + h) * T + q] = sum > 0.f ? msafe + __logf(sum) : INFINITY;
+            if (a.lse && g == 0)
+                a.lse[a.seq_off ? (row0 + q) * H + h : ((long)b * H + h) * T + q] = sum > 0.f ? msafe + __logf(sum) : INFINITY;
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -196,7 +203,14 @@ template <int HD, int NWB>
 __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj_attn_bwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = a.T, H = a.H, D = H * HD;
+    const int H = a.H, D = H * HD;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    int T = a.T;
+    long row0 = (long)b * a.T;
+    if (a.seq_off) {
+        row0 = a.seq_off[b];
+        T = min(a.seq_off[b + 1] - (int)row0, a.T);
+    }
     const int nt = (T + 15) / 16, KP = ((T + 31) / 32) * 32, nch = KP / 32;
     char* img0 = smem;                // phase A: K      phase B: Q
     char* img1 = smem + KP * RS;      // phase A: V      phase B: dO
@@ -206,20 +220,19 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
     float* bsum = kvalid + KP;                                     // [3*HD] column sums of dq | dk | dv (in_proj_bias grad)
     for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) bsum[x] = 0.f;
 
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const long ld = 3L * D;
-    const bf16_t* qkv = (const bf16_t*)a.qkv + (long)b * T * ld + h * HD;
-    const bf16_t* dO = (const bf16_t*)a.dout + (long)b * T * D + h * HD;
-    const bf16_t* O = (const bf16_t*)a.out + (long)b * T * D + h * HD;
-    bf16_t* dqkv = (bf16_t*)a.dqkv + (long)b * T * ld + h * HD;
+    const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * ld + h * HD;
+    const bf16_t* dO = (const bf16_t*)a.dout + row0 * D + h * HD;
+    const bf16_t* O = (const bf16_t*)a.out + row0 * D + h * HD;
+    bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HD;
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
     fill_images2<HD, NWB>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
         float l = INFINITY, dl = 0.f, kv = 0.f;
         if (r < T) {
-            l = a.lse[((long)b * H + h) * T + r];
+            l = a.lse[a.seq_off ? (row0 + r) * H + h : ((long)b * H + h) * T + r];
             kv = (km && km[r]) ? 0.f : 1.f;
 #pragma unroll
             for (int c = 0; c < HD / 8; ++c) {
@@ -417,6 +430,7 @@ int set_lds(K kern, int bytes) {
 extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
     if (!a || !a->qkv || !a->out) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
+    if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     const int KP = ((a->T + 31) / 32) * 32;
     const int lds = 2 * KP * (a->hd * 2 + 32) + KP * 4;
@@ -437,6 +451,7 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
 extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->dqkv) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
+    if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     if (a->dbias && !a->dbias_ws) return WJ_ERR_ARG;
     const int KP = ((a->T + 31) / 32) * 32;

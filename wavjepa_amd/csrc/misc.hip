@@ -116,6 +116,33 @@ __global__ __launch_bounds__(256) void scatter_fill_kernel(wj_scatter_fill_args 
     }
 }
 
+// ragged form: one packed output row per listed dense index (b*G+g)*T + t
+__global__ __launch_bounds__(256) void scatter_fill_rows_kernel(wj_scatter_fill_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D;
+    for (int r = blockIdx.x * 4 + wave; r < a.n_rows; r += gridDim.x * 4) {
+        const int dense = a.rows[r];
+        const int bg = dense / a.T, t = dense - bg * a.T, b = bg / a.G;
+        const int src = a.inv[b * a.T + t];
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 tok;
+            if (src >= 0) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.ctx_feats + (long)src * D + c);
+                tok = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+            } else {
+                const f32x4 mt = *reinterpret_cast<const f32x4*>(a.mask_token + c);
+                tok = f32x4{bf2f(f2bf(mt[0])), bf2f(f2bf(mt[1])), bf2f(f2bf(mt[2])), bf2f(f2bf(mt[3]))};
+            }
+            const f32x4 y = tok + *reinterpret_cast<const f32x4*>(a.pos + (long)t * D + c);
+            bf16x4 yb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yb[e] = f2bf(y[e]);
+            if (a.out_f32) *reinterpret_cast<f32x4*>(a.out_f32 + (long)r * D + c) = y;
+            if (a.out_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.out_bf16 + (long)r * D + c) = yb;
+        }
+    }
+}
+
 constexpr int SFB_ROWS = 64;  // rows per workgroup in the backward
 __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_bwd_args a) {
     __shared__ float macc[1024];
@@ -137,8 +164,11 @@ __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_b
             const int c = lane * 4 + 256 * j;
             if (c < D) {
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int g = 0; g < a.G; ++g)
-                    s += *reinterpret_cast<const f32x4*>(a.d_in + (((long)b * a.G + g) * a.T + t) * D + c);
+                for (int g = 0; g < a.G; ++g) {
+                    long row = ((long)b * a.G + g) * a.T + t;
+                    if (a.rowmap) row = a.rowmap[row];        // ragged: packed row of this token, -1 = not visible
+                    if (row >= 0) s += *reinterpret_cast<const f32x4*>(a.d_in + row * D + c);
+                }
                 if (dst >= 0) {
                     bf16x4 o;
 #pragma unroll
@@ -163,19 +193,30 @@ __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_b
         for (int c = threadIdx.x; c < D; c += 256) atomicAdd(a.d_mask_token + c, macc[c]);
 }
 
-// dst_f32[m] = inv[m] >= 0 ? f32(src_bf16[inv[m]]) : 0     (gradient of the mask gather, jepa.py:399)
+// dst[m] = inv[m] >= 0 ? src[inv[m]] : 0     (gradient of the mask gather, jepa.py:399; inv == NULL: identity)
 __global__ __launch_bounds__(256) void unmask_rows_kernel(wj_unmask_rows_args a) {
     const int D4 = a.D / 4;
     const long n = (long)a.M * D4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int m = (int)(i / D4), c = (int)(i - (long)m * D4) * 4;
-        const int src = a.inv[m];
+        const int src = a.inv ? a.inv[m] : m;
         f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
         if (src >= 0) {
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.src + (long)src * a.D + c);
-            y = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+            if (a.src_is_f32) {
+                y = *reinterpret_cast<const f32x4*>((const float*)a.src + (long)src * a.D + c);
+            } else {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.src + (long)src * a.D + c);
+                y = f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+            }
         }
-        *reinterpret_cast<f32x4*>(a.dst + (long)m * a.D + c) = y;
+        if (a.dst_is_bf16) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(y[e]);
+            *reinterpret_cast<bf16x4*>((bf16_t*)a.dst + (long)m * a.D + c) = o;
+        } else {
+            *reinterpret_cast<f32x4*>((float*)a.dst + (long)m * a.D + c) = y;
+        }
     }
 }
 
@@ -222,14 +263,15 @@ __global__ __launch_bounds__(1024) void mse_count_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(256) void mse_rows_kernel(wj_mse_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = a.D;
-    const long R = (long)a.B * a.G * a.T;
+    const long R = a.rows ? (long)a.n_rows : (long)a.B * a.G * a.T;
     const float count = a.workspace[1];
     const float gk = 2.0f / ((float)D * (count + 1e-8f)) * a.gscale * (a.gscale_ptr ? a.gscale_ptr[0] : 1.0f);
     for (long r = blockIdx.x * 4L + wave; r < R; r += gridDim.x * 4L) {
-        const int t = (int)(r % a.T);
-        const long bg = r / a.T;
+        const long dense = a.rows ? (long)a.rows[r] : r;     // (b*G+g)*T + t; preds / dpreds are indexed by r
+        const int t = (int)(dense % a.T);
+        const long bg = dense / a.T;
         const int b = (int)(bg / a.G);
-        const bool on = a.tgt[r] != 0;
+        const bool on = a.tgt[dense] != 0;
         float err = 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             bf16x4 dp;
@@ -440,6 +482,13 @@ extern "C" int wj_mask_scatter_fill_pos(const wj_scatter_fill_args* a, void* str
     if (!a || !a->ctx_feats || !a->inv || !a->mask_token || !a->pos || a->B <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3) ||
         a->G <= 0)
         return WJ_ERR_ARG;
+    if (a->rows) {
+        if (a->n_rows < 0) return WJ_ERR_ARG;
+        if (a->n_rows == 0) return WJ_OK;
+        hipLaunchKernelGGL(scatter_fill_rows_kernel, dim3(grid_for((long)a->n_rows, 4)), dim3(256), 0, STREAM, *a);
+        WJ_CHECK_LAUNCH();
+        return WJ_OK;
+    }
     hipLaunchKernelGGL(scatter_fill_kernel, dim3(grid_for((long)a->B * a->T, 4)), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
@@ -456,7 +505,7 @@ extern "C" int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args* a, v
 }
 
 extern "C" int wj_unmask_rows_f32(const wj_unmask_rows_args* a, void* stream) {
-    if (!a || !a->src || !a->inv || !a->dst || a->M <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
+    if (!a || !a->src || !a->dst || a->M <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(unmask_rows_kernel, dim3(grid_for((long)a->M * a->D / 4, 256)), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
@@ -472,9 +521,11 @@ extern "C" int wj_instnorm_accumulate(const wj_instnorm_args* a, void* stream) {
 extern "C" int wj_masked_mse(const wj_mse_args* a, void* stream) {
     if (!a || !a->preds || !a->targets || !a->tgt || !a->loss || !a->workspace) return WJ_ERR_ARG;
     if (a->B <= 0 || a->G <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
-    const long R = (long)a->B * a->G * a->T;
-    hipLaunchKernelGGL(mse_count_kernel, dim3(1), dim3(1024), 0, STREAM, a->tgt, a->workspace, R);
-    hipLaunchKernelGGL(mse_rows_kernel, dim3(grid_for(R, 4)), dim3(256), 0, STREAM, *a);
+    const long Rd = (long)a->B * a->G * a->T;          // dense positions (the target count runs over all of them)
+    if (a->rows && a->n_rows < 0) return WJ_ERR_ARG;
+    const long R = a->rows ? (long)a->n_rows : Rd;    // rows actually held by preds / dpreds
+    hipLaunchKernelGGL(mse_count_kernel, dim3(1), dim3(1024), 0, STREAM, a->tgt, a->workspace, Rd);
+    if (R > 0) hipLaunchKernelGGL(mse_rows_kernel, dim3(grid_for(R, 4)), dim3(256), 0, STREAM, *a);
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(1024), 0, STREAM, a->workspace, a->loss, R);
     WJ_CHECK_LAUNCH();
     return WJ_OK;

@@ -49,33 +49,51 @@ class MaskPlan:
     keep: torch.Tensor      # int32 [n_ctx] flat (b*T+t) of context rows, ascending
     inv: torch.Tensor       # int32 [N*T]  position in `keep` or -1
     n_ctx: int
+    # ragged execution (visible tokens only).  The student's non-context rows are dropped by jepa.py:399 and the
+    # predictor's non-target rows carry zero loss weight (jepa.py:356); being key-masked they influence nothing else,
+    # so the student runs on the n_ctx context rows and the predictor on the n_dec visible rows, packed per sequence.
+    enc_off: Optional[torch.Tensor] = None    # int32 [N+1]     context rows before clip b
+    dec_rows: Optional[torch.Tensor] = None   # int32 [n_dec]   dense (b*G+g)*T+t of every visible predictor row, ascending
+    dec_off: Optional[torch.Tensor] = None    # int32 [N*G+1]
+    dec_map: Optional[torch.Tensor] = None    # int32 [N*G*T]   packed row of a dense position or -1
+    n_dec: int = 0
+    max_enc: int = 0                          # longest context / visible sequence (attention length bound)
+    max_dec: int = 0
+    ragged_ok: bool = False                   # False when a target position is key-masked: the dense path must be used
 
 
 def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
     """Build the plan.  CPU masks (the data-loader case) need no device synchronisation."""
     if isinstance(ctx_mask, torch.Tensor) and ctx_mask.is_cuda:
-        ctx_np = None
-        ctx_dev = ctx_mask.to(torch.bool)
-        keep = torch.nonzero(~ctx_dev.reshape(-1)).squeeze(1).to(torch.int32)   # device sync, like the reference's x[~mask]
-        n_ctx = int(keep.numel())
-        inv = torch.full((ctx_dev.numel(),), -1, dtype=torch.int32, device=device)
-        inv[keep.long()] = torch.arange(n_ctx, dtype=torch.int32, device=device)
-        ctx_u8 = ctx_dev.to(torch.uint8).contiguous()
-        tgt_u8 = target_indices.to(torch.uint8).contiguous()
-        vis_u8 = vis_mask.to(torch.uint8).reshape(-1, vis_mask.shape[-1]).contiguous()
-        return MaskPlan(ctx_u8, tgt_u8, vis_u8, keep, inv, n_ctx)
+        # device masks: the index lists need their sizes on the host, like the reference's x[~mask] (one sync)
+        ctx_mask, target_indices, vis_mask = ctx_mask.cpu(), target_indices.cpu(), vis_mask.cpu()
     ctx_np = np.ascontiguousarray(np.asarray(ctx_mask, dtype=bool))
     tgt_np = np.ascontiguousarray(np.asarray(target_indices, dtype=bool))
     vis_np = np.ascontiguousarray(np.asarray(vis_mask, dtype=bool))
+    vis_np = vis_np.reshape(-1, vis_np.shape[-1])
     keep_np = np.flatnonzero(~ctx_np.reshape(-1)).astype(np.int32)
     inv_np = np.full(ctx_np.size, -1, dtype=np.int32)
     inv_np[keep_np] = np.arange(keep_np.size, dtype=np.int32)
+    # ragged index lists
+    ctx_len = (~ctx_np).sum(axis=-1)
+    enc_off = np.concatenate([[0], np.cumsum(ctx_len)]).astype(np.int32)
+    seen = ~vis_np                                             # [N*G, T] rows the predictor computes
+    dec_rows = np.flatnonzero(seen.reshape(-1)).astype(np.int32)
+    dec_len = seen.sum(axis=-1)
+    dec_off = np.concatenate([[0], np.cumsum(dec_len)]).astype(np.int32)
+    dec_map = np.full(seen.size, -1, dtype=np.int32)
+    dec_map[dec_rows] = np.arange(dec_rows.size, dtype=np.int32)
+    ragged_ok = (tgt_np.reshape(vis_np.shape).shape == vis_np.shape
+                 and not bool(np.any(tgt_np.reshape(vis_np.shape) & vis_np)))   # every target row is also a key
 
     def up(a, dt):
-        return torch.from_numpy(a.astype(dt)).to(device, non_blocking=True)
+        return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device, non_blocking=True)
 
-    return MaskPlan(up(ctx_np, np.uint8), up(tgt_np, np.uint8), up(vis_np.reshape(-1, vis_np.shape[-1]), np.uint8),
-                    up(keep_np, np.int32), up(inv_np, np.int32), int(keep_np.size))
+    return MaskPlan(up(ctx_np, np.uint8), up(tgt_np, np.uint8), up(vis_np, np.uint8), up(keep_np, np.int32), up(inv_np, np.int32),
+                    int(keep_np.size), enc_off=up(enc_off, np.int32), dec_rows=up(dec_rows, np.int32),
+                    dec_off=up(dec_off, np.int32), dec_map=up(dec_map, np.int32), n_dec=int(dec_rows.size),
+                    max_enc=int(ctx_len.max()) if ctx_len.size else 0, max_dec=int(dec_len.max()) if dec_len.size else 0,
+                    ragged_ok=ragged_ok)
 
 
 def conv_geometry(n_samples: int, spec) -> Tuple[List[int], List[int]]:
@@ -143,6 +161,10 @@ class JepaEngine:
         # backward) runs beside the main chain and fills the tails / write bursts of its kernels (WJ_SIDE_STREAM=0: off)
         import os as _os
         self.use_side = _os.environ.get("WJ_SIDE_STREAM", "1") != "0"
+        # visible-token (ragged) execution of the student and the predictor; WJ_RAGGED=0 keeps the reference's dense
+        # key-masked shapes (identical loss and gradients, ~2x the work)
+        self.ragged = _os.environ.get("WJ_RAGGED", "1") != "0"
+        self.ragged_step = False
         self.side = torch.cuda.Stream(device=self.dev)
         self._ev = [torch.cuda.Event() for _ in range(8)]
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
@@ -259,6 +281,8 @@ class JepaEngine:
         self.enc_acts = self._alloc_stack(M, c.d_enc, c.h_enc, N, c.l_enc)
         self.dec_acts = self._alloc_stack(Mp, c.d_dec, c.h_dec, N * G, c.l_dec)
         self.ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)       # gathered context rows (<= M)
+        self.enc_in = torch.empty(M, c.d_enc, dtype=f32, device=dev)      # ragged: local features of the context rows
+        self.enc_in_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
         self.cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)           # contextual_features
         self.dec_in = torch.empty(Mp, c.d_dec, dtype=f32, device=dev)
         self.dec_in_b = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
@@ -291,11 +315,15 @@ class JepaEngine:
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
-                   mask: Optional[torch.Tensor]) -> None:
-        """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1))))."""
+                   mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None) -> None:
+        """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1)))).
+        `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask."""
         eps = self.cfg.ln_eps
         ops.gemm(xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, lda=D, ldb=D, ldc=3 * D, bias=w.bqkv)
-        ops.attn_fwd(a.qkv, a.o, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, lse=a.lse)
+        if seq is not None:
+            ops.attn_fwd(a.qkv, a.o, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], lse=a.lse)
+        else:
+            ops.attn_fwd(a.qkv, a.o, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, lse=a.lse)
         ops.gemm(a.o, w.wo, a.p, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, bias=w.bo)
         ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1)
         ops.gemm(a.x1b, w.w1, a.h, C2=a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2)
@@ -326,7 +354,8 @@ class JepaEngine:
             torch.cuda.current_stream().wait_event(ev)
 
     def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dx_out: torch.Tensor,
-                   M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int) -> None:
+                   M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int,
+                   seq: Optional[Tuple[torch.Tensor, int]] = None) -> None:
         """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer.
         The four weight-gradient GEMMs only need (dY, X) and nothing downstream needs them before the optimiser: they run on
         the side stream while the main stream continues the dgrad chain."""
@@ -347,7 +376,10 @@ class JepaEngine:
         ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb1, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
                           workspace=self.red_ws)
         ops.gemm(dsb1, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
-        ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
+        if seq is not None:
+            ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], dbias=w.gbqkv, dbias_ws=self.red_ws)
+        else:
+            ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
 
         def wgrad_attn():
             self._wgrad(dsb1, a.o, w.gwo, D, D, M)
@@ -396,30 +428,66 @@ class JepaEngine:
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
         self._on_side(self._teacher_targets)
-        # student encoder (keys restricted to the context)
-        x, xb = self.lf, self.lf_b
-        for w, a in zip(self.enc_layers, self.enc_acts):
-            self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, plan.ctx_u8)
-            x, xb = a.x2, a.x2b
-        ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=M, D=De, eps=c.norm_eps,
-                          y_f32=self.enc_out, y_bf16=self.enc_out_b, mean=self.enc_fm, rstd=self.enc_fr)
+        self.ragged_step = self.ragged and plan.ragged_ok
         n_ctx = plan.n_ctx
-        ops.mask_gather_rows(self.enc_out_b, plan.keep, self.ctx_in, n_rows=n_ctx, D=De, elem_bytes=2)
+        if self.ragged_step:
+            # student encoder on the context rows only, packed per clip (non-context rows are dropped at jepa.py:399 and,
+            # being key-masked, never influence a context row)
+            Me, eseq = n_ctx, (plan.enc_off, max(plan.max_enc, 1))
+            ops.mask_gather_rows(self.lf, plan.keep, self.enc_in, n_rows=n_ctx, D=De, elem_bytes=4)
+            ops.mask_gather_rows(self.lf_b, plan.keep, self.enc_in_b, n_rows=n_ctx, D=De, elem_bytes=2)
+            x, xb = self.enc_in, self.enc_in_b
+            for w, a in zip(self.enc_layers, self.enc_acts):
+                self._layer_fwd(w, a, x, xb, Me, De, c.h_enc, N, None, eseq)
+                x, xb = a.x2, a.x2b
+            ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=Me, D=De, eps=c.norm_eps,
+                              y_bf16=self.ctx_in, mean=self.enc_fm, rstd=self.enc_fr)
+        else:
+            # student encoder over every token (keys restricted to the context), then the boolean-mask gather
+            x, xb = self.lf, self.lf_b
+            for w, a in zip(self.enc_layers, self.enc_acts):
+                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, plan.ctx_u8)
+                x, xb = a.x2, a.x2b
+            ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=M, D=De, eps=c.norm_eps,
+                              y_f32=self.enc_out, y_bf16=self.enc_out_b, mean=self.enc_fm, rstd=self.enc_fr)
+            ops.mask_gather_rows(self.enc_out_b, plan.keep, self.ctx_in, n_rows=n_ctx, D=De, elem_bytes=2)
         ops.gemm(self.ctx_in, f.ptr16("encoder_to_decoder_mapper.weight"), self.cf, M=n_ctx, N=Dd, K=De, lda=De, ldb=De, ldc=Dd,
                  bias=f.ptr32("encoder_to_decoder_mapper.bias"))
-        # predictor over (context U group targets), one batch row per (clip, group)
-        ops.mask_scatter_fill_pos(self.cf, plan.inv, f.ptr32("mask_token"), self.pos_dec, B=N, T=T, D=Dd, G=G,
-                                  out_f32=self.dec_in, out_bf16=self.dec_in_b)
+        # predictor over (context U group targets), one sequence per (clip, group)
+        if self.ragged_step:
+            Md, dseq = plan.n_dec, (plan.dec_off, max(plan.max_dec, 1))
+            ops.mask_scatter_fill_pos(self.cf, plan.inv, f.ptr32("mask_token"), self.pos_dec, B=N, T=T, D=Dd, G=G,
+                                      out_f32=self.dec_in, out_bf16=self.dec_in_b, rows=plan.dec_rows, n_rows=Md)
+        else:
+            Md, dseq = Mp, None
+            ops.mask_scatter_fill_pos(self.cf, plan.inv, f.ptr32("mask_token"), self.pos_dec, B=N, T=T, D=Dd, G=G,
+                                      out_f32=self.dec_in, out_bf16=self.dec_in_b)
         x, xb = self.dec_in, self.dec_in_b
         for w, a in zip(self.dec_layers, self.dec_acts):
-            self._layer_fwd(w, a, x, xb, Mp, Dd, c.h_dec, N * G, plan.vis_u8)
+            self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq)
             x, xb = a.x2, a.x2b
-        ops.layernorm_fwd(x, f.ptr32("decoder.norm.weight"), f.ptr32("decoder.norm.bias"), M=Mp, D=Dd, eps=c.norm_eps,
+        ops.layernorm_fwd(x, f.ptr32("decoder.norm.weight"), f.ptr32("decoder.norm.bias"), M=Md, D=Dd, eps=c.norm_eps,
                           y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr)
-        ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Mp, N=De, K=Dd, lda=Dd, ldb=Dd,
+        ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Md, N=De, K=Dd, lda=Dd, ldb=Dd,
                  ldc=De, bias=f.ptr32("decoder_to_encoder_mapper.bias"))
         self._join_side()               # teacher targets (side stream) are needed by the loss
-        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=N, G=G, T=T, D=De)
+        self._mse(None, None)
+
+    def _mse(self, dpreds, gscale_ptr) -> None:
+        c, plan = self.cfg, self.plan
+        rows = dict(rows=plan.dec_rows, n_rows=plan.n_dec) if self.ragged_step else {}
+        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=self.N, G=c.groups, T=self.T, D=c.d_enc,
+                       dpreds=dpreds, gscale_ptr=gscale_ptr, **rows)
+
+    def dense_preds(self) -> torch.Tensor:
+        """Predictions as the reference shapes them, bf16 [N*G, T, d_enc].  On a ragged step only the visible rows were
+        computed; the others (zero loss weight on the reference, jepa.py:356) read 0."""
+        N, G, T, De = self.N, self.cfg.groups, self.T, self.cfg.d_enc
+        if not self.ragged_step:
+            return self.preds.view(N * G, T, De)
+        out = torch.empty(N * G * T, De, dtype=torch.bfloat16, device=self.dev)
+        ops.unmask_rows_f32(self.preds, self.plan.dec_map, out, M=N * G * T, D=De, src_is_f32=False, dst_is_bf16=True)
+        return out.view(N * G, T, De)
 
     def _teacher_targets(self) -> None:
         c, N, M, De = self.cfg, self.N, self.M, self.cfg.d_enc
@@ -457,23 +525,26 @@ class JepaEngine:
         N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, c.groups, self.C
         De, Dd = c.d_enc, c.d_dec
         f.g32.zero_()
-        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=N, G=G, T=T, D=De, dpreds=self.dpreds,
-                       gscale_ptr=gscale_ptr if gscale_ptr else None)
+        rag = self.ragged_step
+        Md, dseq = (plan.n_dec, (plan.dec_off, max(plan.max_dec, 1))) if rag else (Mp, None)
+        Me, eseq = (plan.n_ctx, (plan.enc_off, max(plan.max_enc, 1))) if rag else (M, None)
+        self._mse(self.dpreds, gscale_ptr if gscale_ptr else None)
         bw = self.bw["dec"]
         # decoder_to_encoder_mapper
-        ops.colsum_bf16(self.dpreds, f.gptr("decoder_to_encoder_mapper.bias"), M=Mp, N=De, ldx=De)
-        self._wgrad(self.dpreds, self.dec_out_b, f.gptr("decoder_to_encoder_mapper.weight"), De, Dd, Mp)
-        ops.gemm(self.dpreds, f.ptr16("decoder_to_encoder_mapper.weight"), bw["dx1"], M=Mp, N=Dd, K=De, lda=De, ldb=Dd, ldc=Dd,
+        ops.colsum_bf16(self.dpreds, f.gptr("decoder_to_encoder_mapper.bias"), M=Md, N=De, ldx=De)
+        self._wgrad(self.dpreds, self.dec_out_b, f.gptr("decoder_to_encoder_mapper.weight"), De, Dd, Md)
+        ops.gemm(self.dpreds, f.ptr16("decoder_to_encoder_mapper.weight"), bw["dx1"], M=Md, N=Dd, K=De, lda=De, ldb=Dd, ldc=Dd,
                  b_trans=1, epilogue=ops.EPI_ADD_F32)
         last = self.dec_acts[-1]
-        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Mp, D=Dd, ds_f32=bw["dy"],
+        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Md, D=Dd, ds_f32=bw["dy"],
                           dgamma=f.gptr("decoder.norm.weight"), dbeta=f.gptr("decoder.norm.bias"), workspace=self.red_ws)
         dy = bw["dy"]
         for i in range(c.l_dec - 1, -1, -1):
             x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
-            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Mp, Dd, c.h_dec, N * G, plan.vis_u8, bw, i & 1)
+            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Md, Dd, c.h_dec, N * G, plan.vis_u8, bw, i & 1, dseq)
         n_ctx = plan.n_ctx
-        ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G)
+        ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
+                                      rowmap=plan.dec_map if rag else None)
         # encoder_to_decoder_mapper (rows = gathered context tokens)
         ops.colsum_bf16(self.d_cf, f.gptr("encoder_to_decoder_mapper.bias"), M=n_ctx, N=Dd, ldx=Dd)
         self._wgrad(self.d_cf, self.ctx_in, f.gptr("encoder_to_decoder_mapper.weight"), Dd, De, n_ctx)
@@ -481,17 +552,27 @@ class JepaEngine:
                  ldc=De, b_trans=1)
         ready("dec")
         bw = self.bw["enc"]
-        ops.unmask_rows_f32(self.d_ctx_in, plan.inv, bw["dx1"], M=M, D=De)
+        if rag:
+            ops.unmask_rows_f32(self.d_ctx_in, None, bw["dx1"], M=Me, D=De)      # packed rows: a widening copy
+        else:
+            ops.unmask_rows_f32(self.d_ctx_in, plan.inv, bw["dx1"], M=M, D=De)
         last = self.enc_acts[-1]
-        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("encoder.norm.weight"), self.enc_fm, self.enc_fr, M=M, D=De, ds_f32=bw["dy"],
+        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("encoder.norm.weight"), self.enc_fm, self.enc_fr, M=Me, D=De, ds_f32=bw["dy"],
                           dgamma=f.gptr("encoder.norm.weight"), dbeta=f.gptr("encoder.norm.bias"), workspace=self.red_ws)
         dy = bw["dy"]
         for i in range(c.l_enc - 1, -1, -1):
-            x_in, xb_in = (self.lf, self.lf_b) if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
-            self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, M, De, c.h_enc, N, plan.ctx_u8, bw, i & 1)
+            first = (self.enc_in, self.enc_in_b) if rag else (self.lf, self.lf_b)
+            x_in, xb_in = first if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
+            self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, Me, De, c.h_enc, N, plan.ctx_u8, bw, i & 1, eseq)
             ready(f"enc:{i}")
-        # dy = d(local_features) fp32.  The teacher branch is detached (jepa.py:408).
-        ops.cast_f32_to_bf16(dy, self.d_lf_b, M * De)
+        # dy = d(local_features) fp32 (zero on non-context rows).  The teacher branch is detached (jepa.py:408).
+        if rag:
+            ops.unmask_rows_f32(dy, plan.inv, self.d_lf_b, M=M, D=De, src_is_f32=True, dst_is_bf16=True)
+            if not self.has_mapper:
+                ops.unmask_rows_f32(dy, plan.inv, self.d_fn, M=M, D=De, src_is_f32=True)
+                dy = self.d_fn
+        else:
+            ops.cast_f32_to_bf16(dy, self.d_lf_b, M * De)
         if self.has_mapper:
             ops.colsum_bf16(self.d_lf_b, f.gptr("post_extraction_mapper.bias"), M=M, N=De, ldx=De)
             self._wgrad(self.d_lf_b, self.fn_b, f.gptr("post_extraction_mapper.weight"), De, C, M)

@@ -79,6 +79,31 @@ class TransformerStack(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------------
 # Autograd bridge: loss.backward() runs the engine's hand-written backward into the flat gradient buffer
 # ---------------------------------------------------------------------------------------------------------------------
+class _StepOutputs(dict):
+    """The reference's ForwardReturn (a plain dict).  `preds` in the reference's dense [N*G, T, D] shape is materialised
+    on first access: the training loop never reads it, and on a ragged step the engine holds only the visible rows
+    (the others, which carry zero loss weight at reference jepa.py:356, read 0)."""
+
+    def __init__(self, engine, **items):
+        super().__init__(**items)
+        self._engine, self._plan = engine, engine.plan
+
+    def __missing__(self, key):
+        if key != "preds":
+            raise KeyError(key)
+        if self._engine.plan is not self._plan:
+            raise RuntimeError("preds belongs to an earlier step: read it before the next forward overwrites the arena")
+        value = self._engine.dense_preds()
+        self[key] = value
+        return value
+
+    def __contains__(self, key):
+        return key == "preds" or super().__contains__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class _EngineLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor: torch.Tensor, module: "JEPA") -> torch.Tensor:
@@ -359,8 +384,8 @@ class JEPA(nn.Module):
             loss = _EngineLoss.apply(self._anchor, self)
         else:
             loss = eng.loss[0].clone()
-        return ForwardReturn(local_features=eng.lf.view(N, T, -1), contextual_features=eng.cf[:plan.n_ctx], loss=loss,
-                             preds=eng.preds.view(N * G, T, -1), targets=eng.targets.view(N, T, -1))
+        return _StepOutputs(eng, local_features=eng.lf.view(N, T, -1), contextual_features=eng.cf[:plan.n_ctx], loss=loss,
+                            targets=eng.targets.view(N, T, -1))
 
     @torch.no_grad()
     def get_audio_representation(self, audio: torch.Tensor, padding_mask: Optional[torch.Tensor]) -> torch.Tensor:

@@ -108,14 +108,16 @@ def colsum_f32(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[i
 
 # ---------------------------------------------------------------------------------------------------------- attention
 def attn_fwd(qkv: Ptr, out: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None, lse: Ptr = None,
-             mask_group: int = 1, stream: Optional[int] = None) -> None:
-    _run("wj_attn_fwd", "wj_attn_fwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), out=_p(out), lse=_p(lse), B=B, T=T,
-         H=H, hd=hd, mask_group=mask_group)
+             mask_group: int = 1, seq_off: Ptr = None, stream: Optional[int] = None) -> None:
+    """seq_off (int32 [B+1]) selects the ragged form: packed sequences, T = length bound, lse [rows][H]."""
+    _run("wj_attn_fwd", "wj_attn_fwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), seq_off=_p(seq_off), out=_p(out),
+         lse=_p(lse), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
 
 
 def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None,
-             mask_group: int = 1, dbias: Ptr = None, dbias_ws: Ptr = None, stream: Optional[int] = None) -> None:
-    _run("wj_attn_bwd", "wj_attn_bwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), out=_p(out), dout=_p(dout),
+             mask_group: int = 1, dbias: Ptr = None, dbias_ws: Ptr = None, seq_off: Ptr = None,
+             stream: Optional[int] = None) -> None:
+    _run("wj_attn_bwd", "wj_attn_bwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), seq_off=_p(seq_off), out=_p(out), dout=_p(dout),
          lse=_p(lse), dqkv=_p(dqkv), dbias=_p(dbias), dbias_ws=_p(dbias_ws), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
 
 
@@ -158,19 +160,25 @@ def mask_gather_rows(x: Ptr, idx: Ptr, out: Ptr, *, n_rows: int, D: int, elem_by
 
 
 def mask_scatter_fill_pos(ctx_feats: Ptr, inv: Ptr, mask_token: Ptr, pos: Ptr, *, B: int, T: int, D: int, G: int,
-                          out_f32: Ptr = None, out_bf16: Ptr = None, stream: Optional[int] = None) -> None:
+                          out_f32: Ptr = None, out_bf16: Ptr = None, rows: Ptr = None, n_rows: int = 0,
+                          stream: Optional[int] = None) -> None:
+    """rows (int32 [n_rows] of dense (b*G+g)*T+t) selects the ragged form: only those rows, packed."""
     _run("wj_mask_scatter_fill_pos", "wj_scatter_fill_args", stream, ctx_feats=_p(ctx_feats), inv=_p(inv),
-         mask_token=_p(mask_token), pos=_p(pos), out_f32=_p(out_f32), out_bf16=_p(out_bf16), B=B, T=T, D=D, G=G)
+         mask_token=_p(mask_token), pos=_p(pos), rows=_p(rows), out_f32=_p(out_f32), out_bf16=_p(out_bf16), B=B, T=T, D=D, G=G,
+         n_rows=n_rows)
 
 
 def mask_scatter_fill_pos_bwd(d_in: Ptr, inv: Ptr, d_ctx_feats: Ptr, d_mask_token: Ptr, *, B: int, T: int, D: int, G: int,
-                              stream: Optional[int] = None) -> None:
-    _run("wj_mask_scatter_fill_pos_bwd", "wj_scatter_fill_bwd_args", stream, d_in=_p(d_in), inv=_p(inv),
+                              rowmap: Ptr = None, stream: Optional[int] = None) -> None:
+    _run("wj_mask_scatter_fill_pos_bwd", "wj_scatter_fill_bwd_args", stream, d_in=_p(d_in), inv=_p(inv), rowmap=_p(rowmap),
          d_ctx_feats=_p(d_ctx_feats), d_mask_token=_p(d_mask_token), B=B, T=T, D=D, G=G)
 
 
-def unmask_rows_f32(src: Ptr, inv: Ptr, dst: Ptr, *, M: int, D: int, stream: Optional[int] = None) -> None:
-    _run("wj_unmask_rows_f32", "wj_unmask_rows_args", stream, src=_p(src), inv=_p(inv), dst=_p(dst), M=M, D=D)
+def unmask_rows_f32(src: Ptr, inv: Ptr, dst: Ptr, *, M: int, D: int, src_is_f32: bool = False, dst_is_bf16: bool = False,
+                    stream: Optional[int] = None) -> None:
+    """dst[m] = inv[m] >= 0 ? src[inv[m]] : 0 (bf16 -> f32 unless the flags say otherwise; inv None = identity)."""
+    _run("wj_unmask_rows_f32", "wj_unmask_rows_args", stream, src=_p(src), inv=_p(inv), dst=_p(dst), M=M, D=D,
+         src_is_f32=int(src_is_f32), dst_is_bf16=int(dst_is_bf16))
 
 
 # ---------------------------------------------------------------------------------------------------------- targets / loss
@@ -181,9 +189,10 @@ def instnorm_accumulate(x: Ptr, targets: Ptr, *, B: int, TD: int, accumulate: bo
 
 
 def masked_mse(preds: Ptr, targets: Ptr, tgt: Ptr, loss: Ptr, workspace: Ptr, *, B: int, G: int, T: int, D: int,
-               dpreds: Ptr = None, gscale: float = 1.0, gscale_ptr: Ptr = None, stream: Optional[int] = None) -> None:
-    _run("wj_masked_mse", "wj_mse_args", stream, preds=_p(preds), targets=_p(targets), tgt=_p(tgt), loss=_p(loss),
-         dpreds=_p(dpreds), workspace=_p(workspace), gscale_ptr=_p(gscale_ptr), B=B, G=G, T=T, D=D, gscale=gscale)
+               dpreds: Ptr = None, gscale: float = 1.0, gscale_ptr: Ptr = None, rows: Ptr = None, n_rows: int = 0,
+               stream: Optional[int] = None) -> None:
+    _run("wj_masked_mse", "wj_mse_args", stream, preds=_p(preds), targets=_p(targets), tgt=_p(tgt), rows=_p(rows), loss=_p(loss),
+         dpreds=_p(dpreds), workspace=_p(workspace), gscale_ptr=_p(gscale_ptr), B=B, G=G, T=T, D=D, n_rows=n_rows, gscale=gscale)
 
 
 # ---------------------------------------------------------------------------------------------------------- optimiser side
