@@ -50,7 +50,7 @@ def build_model(device, seed: int):
 
 
 def gemm_kernel_name(f) -> str:
-    epi = {0: "BF16", 1: "BIAS_GELU2", 2: "MUL_GELU_GRAD", 3: "ADD_F32", 4: "ATOMIC_F32", 5: "CONV_GELU"}[f["epilogue"]]
+    epi = {0: "BF16", 1: "BIAS_GELU2", 2: "MUL_GELU_GRAD", 3: "ADD_F32", 4: "ATOMIC_F32", 5: "CONV_GELU", 6: "BIAS_GELU"}[f["epilogue"]]
     return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
 
 

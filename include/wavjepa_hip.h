@@ -43,7 +43,8 @@ enum {
     WJ_EPI_MUL_GELU_GRAD = 2, /* C(bf16)  = bf16(acc) * aux(bf16), aux = the gelu'(h) saved by EPI 1 (backward through GELU) */
     WJ_EPI_ADD_F32 = 3,       /* C(f32)   = acc (+ aux(f32))                       (dgrad + residual-stream)   */
     WJ_EPI_ATOMIC_F32 = 4,    /* C(f32)  += alpha * acc   (atomic; split_k >= 1)   (wgrad into the grad buffer) */
-    WJ_EPI_CONV_GELU = 5      /* C(bf16)  = pre = bf16(acc); C2(bf16) = gelu(pre); rows (m % seg_rows) >= seg_valid -> 0 */
+    WJ_EPI_CONV_GELU = 5,     /* C(bf16)  = pre = bf16(acc); C2(bf16) = gelu(pre); rows (m % seg_rows) >= seg_valid -> 0 */
+    WJ_EPI_BIAS_GELU = 6      /* C(bf16)  = gelu(bf16(acc + bias))      (linear1 + nn.GELU where no backward follows: teacher) */
 };
 typedef struct {
     const void* A;

@@ -75,6 +75,11 @@ def test_gemm_bias_gelu2(ops):
     F.gelu(hr).sum().backward()
     assert relerr(G.float(), F.gelu(h)) < 6e-3                            # C2 = gelu(h)
     assert relerr(H.float(), hr.grad) < 6e-3                              # C  = gelu'(h), what the backward needs of h
+    # elementwise: the fast erf (A&S 7.1.26, v_rcp) stays within one bf16 ulp of torch's erf-GELU
+    assert maxerr(G.float(), F.gelu(h)) <= 2.0 ** -8 * float(F.gelu(h).abs().max())
+    G1 = torch.empty_like(G)                                              # single-output form (teacher / inference)
+    ops.gemm(A, W, G1, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=ops.EPI_BIAS_GELU)
+    assert torch.equal(G1, G)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 136, 192), (512, 768, 3072)])

@@ -29,6 +29,31 @@ SHAPES = [
     ("enc dW1       TT", 1, 1, ops.EPI_ATOMIC_F32, 3072, 768, 51200),
     ("enc dW2       TT", 1, 1, ops.EPI_ATOMIC_F32, 768, 3072, 51200),
     ("dec dW1       TT", 1, 1, ops.EPI_ATOMIC_F32, 1536, 384, 204800),
+    # ragged step (AudioSet masker, 256 clips): ~9.9k context rows for the student, ~86k visible rows for the predictor
+    ("rag enc qkv   NN", 0, 0, ops.EPI_BF16, 9907, 2304, 768),
+    ("rag enc out   NN", 0, 0, ops.EPI_BF16, 9907, 768, 768),
+    ("rag enc lin1  NN", 0, 0, ops.EPI_BIAS_GELU2, 9907, 3072, 768),
+    ("rag enc lin2  NN", 0, 0, ops.EPI_BF16, 9907, 768, 3072),
+    ("rag enc dh    NT", 0, 1, ops.EPI_MUL_GELU_GRAD, 9907, 3072, 768),
+    ("rag enc dx1   NT", 0, 1, ops.EPI_ADD_F32, 9907, 768, 3072),
+    ("rag enc dxin  NT", 0, 1, ops.EPI_ADD_F32, 9907, 768, 2304),
+    ("rag enc do    NT", 0, 1, ops.EPI_BF16, 9907, 768, 768),
+    ("rag enc dWqkv TT", 1, 1, ops.EPI_ATOMIC_F32, 2304, 768, 9907),
+    ("rag enc dW1   TT", 1, 1, ops.EPI_ATOMIC_F32, 3072, 768, 9907),
+    ("rag enc dW2   TT", 1, 1, ops.EPI_ATOMIC_F32, 768, 3072, 9907),
+    ("rag enc dWo   TT", 1, 1, ops.EPI_ATOMIC_F32, 768, 768, 9907),
+    ("rag dec qkv   NN", 0, 0, ops.EPI_BF16, 86317, 1152, 384),
+    ("rag dec out   NN", 0, 0, ops.EPI_BF16, 86317, 384, 384),
+    ("rag dec lin1  NN", 0, 0, ops.EPI_BIAS_GELU2, 86317, 1536, 384),
+    ("rag dec lin2  NN", 0, 0, ops.EPI_BF16, 86317, 384, 1536),
+    ("rag dec dh    NT", 0, 1, ops.EPI_MUL_GELU_GRAD, 86317, 1536, 384),
+    ("rag dec dx1   NT", 0, 1, ops.EPI_ADD_F32, 86317, 384, 1536),
+    ("rag dec dxin  NT", 0, 1, ops.EPI_ADD_F32, 86317, 384, 1152),
+    ("rag dec do    NT", 0, 1, ops.EPI_BF16, 86317, 384, 384),
+    ("rag dec dWqkv TT", 1, 1, ops.EPI_ATOMIC_F32, 1152, 384, 86317),
+    ("rag dec dW1   TT", 1, 1, ops.EPI_ATOMIC_F32, 1536, 384, 86317),
+    ("rag dec dW2   TT", 1, 1, ops.EPI_ATOMIC_F32, 384, 1536, 86317),
+    ("rag dec dWo   TT", 1, 1, ops.EPI_ATOMIC_F32, 384, 384, 86317),
     ("conv1 fwd     NN", 0, 0, ops.EPI_CONV_GELU, 256 * 3216, 512, 1536),
     ("conv1 wgrad   TT", 1, 1, ops.EPI_ATOMIC_F32, 512, 1536, 256 * 3216),
 ]

@@ -54,7 +54,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& e) {
     // returns erf(|x|/sqrt2) and e = exp(-x^2/2)
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn is a ~10-instruction IEEE divide
     e = __expf(-z * z);
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);

@@ -406,16 +406,23 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                 } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
                     // h = v (bf16).  Stored: C = gelu'(h) (all the backward needs of h: one multiply there, no erf/exp),
                     // C2 = gelu(h); both from the same erf and exp.
+                    // WJ_EPI_BIAS_GELU (forward only, e.C2 == NULL): C = gelu(h) and nothing else.
                     bf16x8 gl, gp;
+                    if (e.C2) {                                   // kernel-uniform
 #pragma unroll
-                    for (int x = 0; x < 8; ++x) {
-                        float g0, g1;
-                        gelu_both_f(bf2f(v[x]), g0, g1);
-                        gl[x] = f2bf(g0);
-                        gp[x] = f2bf(g1);
+                        for (int x = 0; x < 8; ++x) {
+                            float g0, g1;
+                            gelu_both_f(bf2f(v[x]), g0, g1);
+                            gl[x] = f2bf(g0);
+                            gp[x] = f2bf(g1);
+                        }
+                        *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gp;
+                        *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
+                        *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gl;
                     }
-                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gp;
-                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
                 } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
                     bf16x8 o;
 #pragma unroll
@@ -473,7 +480,7 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     int kps = ((a->K + split - 1) / split + 63) / 64 * 64;
     split = (a->K + kps - 1) / kps;
     EpiArgs e;
-    e.C = a->C; e.C2 = a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc; e.colsum = a->colsum;
+    e.C = a->C; e.C2 = a->epilogue == WJ_EPI_BIAS_GELU ? nullptr : a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc; e.colsum = a->colsum;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
     auto kern = gemm3_kernel<AT, BT, EPI, BN, STAGGER>;
@@ -514,7 +521,8 @@ template <bool AT, bool BT>
 int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
     switch (a->epilogue) {
         case WJ_EPI_BF16: return launch_bn<AT, BT, WJ_EPI_BF16>(a, s);
-        case WJ_EPI_BIAS_GELU2: return launch_bn<AT, BT, WJ_EPI_BIAS_GELU2>(a, s);
+        case WJ_EPI_BIAS_GELU2:
+        case WJ_EPI_BIAS_GELU: return launch_bn<AT, BT, WJ_EPI_BIAS_GELU2>(a, s);   // one instantiation, C2 == NULL selects the single output
         case WJ_EPI_MUL_GELU_GRAD: return launch_bn<AT, BT, WJ_EPI_MUL_GELU_GRAD>(a, s);
         case WJ_EPI_ADD_F32: return launch_bn<AT, BT, WJ_EPI_ADD_F32>(a, s);
         case WJ_EPI_ATOMIC_F32: return launch_bn<AT, BT, WJ_EPI_ATOMIC_F32>(a, s);

@@ -315,18 +315,22 @@ class JepaEngine:
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
-                   mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None) -> None:
+                   mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None, save: bool = True) -> None:
         """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1)))).
-        `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask."""
+        `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask.
+        save=False (teacher / inference): nothing is kept for a backward (no gelu' output, no softmax statistics)."""
         eps = self.cfg.ln_eps
         ops.gemm(xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, lda=D, ldb=D, ldc=3 * D, bias=w.bqkv)
         if seq is not None:
-            ops.attn_fwd(a.qkv, a.o, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], lse=a.lse)
+            ops.attn_fwd(a.qkv, a.o, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], lse=a.lse if save else None)
         else:
-            ops.attn_fwd(a.qkv, a.o, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, lse=a.lse)
+            ops.attn_fwd(a.qkv, a.o, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, lse=a.lse if save else None)
         ops.gemm(a.o, w.wo, a.p, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, bias=w.bo)
         ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1)
-        ops.gemm(a.x1b, w.w1, a.h, C2=a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2)
+        if save:
+            ops.gemm(a.x1b, w.w1, a.h, C2=a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2)
+        else:
+            ops.gemm(a.x1b, w.w1, a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU)
         ops.gemm(a.g, w.w2, a.f, M=M, N=D, K=4 * D, lda=4 * D, ldb=4 * D, ldc=D, bias=w.b2)
         ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2, y_bf16=a.x2b, mean=a.m2, rstd=a.r2)
 
@@ -495,7 +499,7 @@ class JepaEngine:
         x, xb = self.lf, self.lf_b
         kept = 0
         for i, w in enumerate(self.tea_layers):
-            self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None)
+            self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False)
             # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
             # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
             x, xb = a.x2, a.x2b
@@ -630,7 +634,7 @@ class JepaEngine:
         a = self.scratch
         x, xb = self.lf, self.lf_b
         for w in self.enc_layers:
-            self._layer_fwd(w, a, x, xb, self.M, c.d_enc, c.h_enc, N, key_mask_u8)
+            self._layer_fwd(w, a, x, xb, self.M, c.d_enc, c.h_enc, N, key_mask_u8, save=False)
             x, xb = a.x2, a.x2b
         ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=self.M, D=c.d_enc, eps=c.norm_eps,
                           y_f32=self.enc_out)

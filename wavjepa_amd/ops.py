@@ -21,6 +21,7 @@ EPI_MUL_GELU_GRAD = ENUMS["WJ_EPI_MUL_GELU_GRAD"]
 EPI_ADD_F32 = ENUMS["WJ_EPI_ADD_F32"]
 EPI_ATOMIC_F32 = ENUMS["WJ_EPI_ATOMIC_F32"]
 EPI_CONV_GELU = ENUMS["WJ_EPI_CONV_GELU"]
+EPI_BIAS_GELU = ENUMS["WJ_EPI_BIAS_GELU"]
 
 
 def _p(x: Ptr) -> int:
