@@ -55,6 +55,10 @@ typedef struct {
     const void* aux;
     float* colsum;    /* optional f32 [N]: += column sums of the bf16 output C (EPI_BF16 / EPI_MUL_GELU_GRAD): the bias
                          gradient of the Linear whose output-gradient this GEMM produces, fused instead of a re-read */
+    const int32_t* rowmap; /* optional gather list (backward of the conv layers over the rows that carry gradient):
+                         (a_trans=0, b_trans=1, EPI_BF16): int32 [M], logical row m of A and of C is storage row rowmap[m];
+                         (a_trans=1, b_trans=1, EPI_ATOMIC_F32): int32 [K + 256] (padding readable), logical k of A and
+                         of B is storage row rowmap[k].  Other combinations: WJ_ERR_UNSUPPORTED. */
     int64_t lda, ldb, ldc;
     int32_t M, N, K;
     int32_t a_trans, b_trans;
@@ -205,13 +209,25 @@ int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args*, void* stream);
 
 /* dpre(bf16) = dpost(bf16) * gelu'(pre(bf16)), elementwise over n elements (conv layers 1..5 backward through GELU;
  * rows that are padding hold pre = 0, dpost = 0 and stay 0). */
+/* Listed-rows form (rows != NULL; sparse conv backward, DESIGN.md "active rows"): only rows[0..n_rows) of the
+ * [.][row_elems] matrices are processed; with clear_dpost the consumed dpost rows are overwritten with zeros. */
 typedef struct {
-    const void* dpost;
+    void* dpost;
     const void* pre;
     void* dpre;
+    const int32_t* rows;
     int64_t n;
+    int32_t n_rows, row_elems, clear_dpost;
 } wj_gelu_bwd_args;
 int wj_gelu_bwd_bf16(const wj_gelu_bwd_args*, void* stream);
+
+/* buf[rows[i]][0 .. row_bytes) = 0 for i < n_rows (restores the all-zero state of a sparse gradient buffer) */
+typedef struct {
+    void* buf;
+    const int32_t* rows;
+    int32_t n_rows, row_bytes;
+} wj_zero_rows_args;
+int wj_zero_rows(const wj_zero_rows_args*, void* stream);
 
 /* Conv weight layout helpers (reference layout [C_out][C_in][k] f32  <->  GEMM layouts, bf16).
  *   mode 0: wp[o][kk*C_in + c]            = w[o][c][kk]                       (forward, B row form, K = k*C_in)

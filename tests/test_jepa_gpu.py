@@ -162,6 +162,28 @@ def test_ragged_equals_dense_step(golden_dir):
     assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
 
 
+def test_sparse_conv_backward_equals_dense_across_steps(golden_dir):
+    """Conv backward over the active rows only (gather GEMMs) == the dense conv backward, including on a second step
+    with different masks (the gradient buffers must be back to all-zero between steps)."""
+    fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    sets = [tuple(torch.from_numpy(fx[k][i:i + 3]) for k in ("as_ctx", "as_tgt", "as_vis")) for i in (0, 3)]
+    audios = [torch.from_numpy(synth.synth_audio(3, 1, 32159, seed=11 + i)).to(torch.bfloat16).to(dev()) for i in range(2)]
+    grads = {}
+    for sparse in (True, False):
+        m, _ = build(SMALL)
+        eng = m._ensure_engine()
+        eng.sparse_conv = sparse
+        for i in range(2):
+            m.zero_grad(set_to_none=True)
+            out = m(audios[i], *sets[i])
+            out["loss"].backward()
+        assert eng.ragged_step
+        grads[sparse] = {k: p.grad.double().clone() for k, p in m.named_parameters() if k.startswith(("extract_audio", "feature_norms"))}
+    for k, want in grads[False].items():
+        err = float((grads[True][k] - want).norm() / (want.norm() + 1e-30))
+        assert err < 5e-3, (k, err)
+
+
 def test_target_outside_visible_set_falls_back_to_dense(golden_dir):
     """If a target position is key-masked the predictor row must still be computed as a query: such a batch takes the
     dense path (the reference maskers never produce it)."""

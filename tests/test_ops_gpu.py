@@ -120,6 +120,59 @@ def test_gemm_wgrad_layout(ops, Mtok, Nout, Kin, split):
     assert relerr(dW, ref) < 1e-3
 
 
+def test_gemm_gather_forms(ops):
+    """Sparse conv backward GEMMs: logical rows / logical k taken from a row list == the dense GEMM on compacted copies."""
+    g = torch.Generator().manual_seed(20)
+    C, k, s_ = 512, 3, 2
+    rows_out, rows_in = 3000, 6016                                # layer rows (all clips), previous layer rows
+    sel = torch.sort(torch.randperm(rows_out - 4, generator=g)[:700] + 2).values.to(torch.int32).to(dev())
+    n = int(sel.numel())
+    # --- dgrad (row gather): C[rowmap[m]] = A[rowmap[m] .. +U rows] @ W, U = 2 taps spanning consecutive rows
+    U = 2
+    dpre = rnd(rows_out + 8, C, dtype=torch.bfloat16, seed=21)
+    wd = rnd(U * C, C, scale=0.05, dtype=torch.bfloat16, seed=22)
+    out = torch.zeros(rows_in + 16, C, dtype=torch.bfloat16, device=dev())
+    a_ptr = dpre.data_ptr() + (2 - (U - 1)) * C * 2                # logical row g starts at storage row 2 + g - (U-1)
+    ops.gemm(a_ptr, wd, out.data_ptr(), M=n, N=C, K=U * C, lda=C, ldb=C, ldc=s_ * C, b_trans=1, rowmap=sel)
+    A = torch.cat([dpre[1 + sel.long()], dpre[2 + sel.long()]], 1).float()           # rows g-1, g of the logical matrix
+    want = (A @ wd.float()).to(torch.bfloat16)
+    got = out.view(-1)[: (rows_in // s_) * s_ * C].view(-1, s_ * C)[sel.long(), :C]
+    assert relerr(got.float(), want.float()) < 4e-3
+    mask = torch.ones(out.shape[0] * C // (s_ * C), dtype=torch.bool, device=dev())
+    mask[sel.long()] = False
+    assert float(out.view(-1)[: mask.numel() * s_ * C].view(-1, s_ * C)[mask].abs().max()) == 0.0   # nothing else written
+    # --- wgrad (k gather): dW[o][kk*C + c] = sum_{g in list} dY[g][o] * X[s*g + kk][c]
+    dy = rnd(rows_out, C, dtype=torch.bfloat16, seed=23)
+    x = rnd(rows_in + 16, C, scale=0.3, dtype=torch.bfloat16, seed=24)
+    dw = torch.zeros(C, k * C, device=dev())
+    lst = torch.cat([sel, torch.zeros(256, dtype=torch.int32, device=dev())])
+    ops.gemm(dy, x, dw, M=C, N=k * C, K=n, lda=C, ldb=s_ * C, ldc=k * C, a_trans=1, b_trans=1, epilogue=ops.EPI_ATOMIC_F32,
+             split_k=ops.pick_split_k(C, k * C, n), rowmap=lst)
+    X = torch.cat([x[s_ * sel.long() + kk] for kk in range(k)], 1).float()
+    want = dy[sel.long()].float().t() @ X
+    assert relerr(dw, want) < 2e-3
+    from wavjepa_amd._abi import WavJepaHipError
+    with pytest.raises(WavJepaHipError):                          # no gather form for the forward layout
+        ops.gemm(dy, x, out, M=64, N=C, K=C, lda=C, ldb=C, ldc=C, rowmap=sel)
+
+
+def test_gelu_bwd_rows_and_zero_rows(ops):
+    R, C = 500, 512
+    dpost = rnd(R, C, dtype=torch.bfloat16, seed=25)
+    pre = rnd(R, C, dtype=torch.bfloat16, seed=26)
+    dense = torch.empty_like(dpost)
+    ops.gelu_bwd_bf16(dpost, pre, dense, R * C)
+    rows = torch.tensor([0, 3, 4, 77, 499], dtype=torch.int32, device=dev())
+    got = torch.full_like(dpost, 7.0)
+    dp = dpost.clone()
+    ops.gelu_bwd_bf16(dp, pre, got, 0, rows=rows, n_rows=5, row_elems=C, clear_dpost=True)
+    assert torch.equal(got[rows.long()], dense[rows.long()])
+    keep = torch.ones(R, dtype=torch.bool, device=dev()); keep[rows.long()] = False
+    assert bool((got[keep] == 7.0).all()) and torch.equal(dp[keep], dpost[keep]) and float(dp[rows.long()].abs().max()) == 0.0
+    ops.zero_rows(got, rows, n_rows=5, row_bytes=C * 2)
+    assert float(got[rows.long()].abs().max()) == 0.0 and bool((got[keep] == 7.0).all())
+
+
 def test_gemm_conv_overlapping_rows(ops):
     """Conv1d(k=3, s=2) over a channels-last [rows][C] activation = GEMM with lda = 2C, K = 3C (implicit im2col),
     with the CONV_GELU epilogue zeroing the padded rows of every clip."""

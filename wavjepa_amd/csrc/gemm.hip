@@ -68,9 +68,12 @@ __device__ __forceinline__ const bf16_t* sel_ptr(bool ok, const bf16_t* p, const
 __device__ __forceinline__ int row_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }  // h = {0,2,3,1}
 
 // ---- HBM -> LDS: this wave's share of one operand tile (ROWS x 32 k) ----------------------------------------
-template <bool TRANS, int ROWS>
+// Gather forms (sparse conv backward): `gidx` replaces the natural row index of the operand -- for a row-form operand the
+// PER_WAVE storage rows this lane stages (looked up once per workgroup), for a col-form operand the 4 storage k-rows this
+// wave stages of this K tile (wave-uniform scalars).
+template <bool TRANS, int ROWS, bool GATHERED = false>
 __device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restrict__ base, long ld, int r0, int R, int k0,
-                                           int kend, int wave, int lane, const bf16_t* zero) {
+                                           int kend, int wave, int lane, const bf16_t* zero, const int* gidx = nullptr) {
     constexpr int PER_WAVE = ROWS * BK * 2 / 1024 / 8;  // 1-KiB wave-instructions per wave: 2 (256 rows) / 1 (128 rows)
 #pragma unroll
     for (int u = 0; u < PER_WAVE; ++u) {
@@ -82,8 +85,19 @@ __device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restr
             const int c = (lane & 3) ^ row_swz(row);
             int grow = r0 + row;
             grow = grow < R ? grow : R - 1;
+            if constexpr (GATHERED) grow = gidx[u];
             const int k = k0 + c * 8;
             src = sel_ptr(k < kend, base + (long)grow * ld + k, zero);
+        } else if constexpr (GATHERED) {
+            static_assert(!GATHERED || ROWS == 256, "col-form gather is built for 256-wide operand tiles");
+            constexpr int CPR = ROWS / 8;
+            const int krow = j * 2 + (lane >> 5);
+            const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+            const int c = (lane % CPR) ^ (f << 1);
+            const int k = k0 + krow;
+            const int gk = (lane >> 5) ? gidx[2 * u + 1] : gidx[2 * u];
+            const int row = r0 + c * 8;
+            src = sel_ptr(k < kend && row < R, base + (long)gk * ld + row, zero);
         } else {
             // [32 k][ROWS] image: LDS position (k row, chunk p) holds source chunk p ^ (f(k) << 1),
             // f(k) = (k & 3) | ((k >> 3) & 1) << 2  -> the 8 k-rows one transposed read touches hit 8 distinct 32-B columns
@@ -149,6 +163,7 @@ struct EpiArgs {
     long ldc;
     int seg_rows, seg_valid;
     float alpha;
+    const int32_t* rowmap;   // gather forms: storage row of logical row m (GATHER 1) / of logical k (GATHER 2)
 };
 
 template <int N>
@@ -156,12 +171,18 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool AT, bool BT, int EPI, int BN, bool STAGGER>
+// GATHER 0: dense.  1: logical row m of A (row form) and of C lives at storage row rowmap[m] (conv dgrad over the active
+// rows).  2: logical k of A and B (both col form) lives at storage row rowmap[k] (conv wgrad over the active rows;
+// the list is padded with >= 256 readable entries).
+template <bool AT, bool BT, int EPI, int BN, bool STAGGER, int GATHER = 0>
 __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                                       long lda, long ldb, int M, int N, int K, int tiles_n,
                                                                       int split_k, int k_per_split, EpiArgs e) {
     using C_ = Cfg<BN>;
     static_assert(!STAGGER || BN == 256, "the ping-pong schedule is built for the 8-wave 256x256 tile");
+    static_assert(GATHER == 0 || !STAGGER, "gather forms use the plain schedule");
+    static_assert(GATHER != 1 || (!AT && EPI == WJ_EPI_BF16), "row gather: row-form A, bf16 output");
+    static_assert(GATHER != 2 || (AT && BT && BN == 256), "k gather: col-form A and B, 256-wide tiles");
     constexpr int S = C_::STAGES, A_BYTES = C_::A_BYTES, STAGE_BYTES = C_::STAGE_BYTES, LPT = C_::LOADS_PER_TILE, MI = C_::MI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -187,14 +208,40 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // gather indices
+    int arow[2] = {0, 0};                 // GATHER 1: storage rows of the two A rows this lane stages
+    if constexpr (GATHER == 1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lr = m0 + (wave * 2 + u) * 16 + (lane >> 2);
+            arow[u] = e.rowmap[lr < M ? lr : M - 1];
+        }
+    }
+    int kidx[4] = {0, 0, 0, 0};           // GATHER 2: storage k-rows 4*wave .. +3 of the tile about to be staged (scalars)
+    auto load_kidx = [&](int k0) {
+        // wave-uniform address in the CONSTANT address space: an s_load_dwordx4 (lgkmcnt), not a vector load whose
+        // vmcnt wait would drain the LDS-DMA ring
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(4))) const i32x4 const_i32x4;
+        const i32x4 v = *reinterpret_cast<const_i32x4*>(reinterpret_cast<unsigned long long>(e.rowmap + k0 + 4 * wave));
+        kidx[0] = v[0]; kidx[1] = v[1]; kidx[2] = v[2]; kidx[3] = v[3];
+    };
+
     if (nkt > 0) {
 #pragma unroll
         for (int p = 0; p < S - 1; ++p) {
             if (p < nkt) {
-                stage_tile<AT, BM>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero);
-                stage_tile<BT, BN>(smem + p * STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + p * BK, kend, wave, lane, zero);
+                if constexpr (GATHER == 2) {
+                    load_kidx(kbeg + p * BK);
+                    stage_tile<AT, BM, true>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero, kidx);
+                    stage_tile<BT, BN, true>(smem + p * STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + p * BK, kend, wave, lane, zero, kidx);
+                } else {
+                    stage_tile<AT, BM, GATHER == 1>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero, arow);
+                    stage_tile<BT, BN>(smem + p * STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + p * BK, kend, wave, lane, zero);
+                }
             }
         }
+        if constexpr (GATHER == 2) load_kidx(kbeg + (S - 1) * BK);   // indices of the tile staged in iteration 0
         int cur = 0;                      // stage holding tile kt
         if constexpr (!STAGGER) {
             for (int kt = 0; kt < nkt; ++kt) {
@@ -209,8 +256,14 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                     const int nxt = cur == 0 ? S - 1 : cur - 1;   // (cur + S - 1) % S
                     char* st = smem + nxt * STAGE_BYTES;
                     const int k0 = kbeg + (kt + S - 1) * BK;
-                    stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
-                    stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+                    if constexpr (GATHER == 2) {
+                        stage_tile<AT, BM, true>(st, A, lda, m0, M, k0, kend, wave, lane, zero, kidx);
+                        stage_tile<BT, BN, true>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero, kidx);
+                        load_kidx(k0 + BK);                       // next iteration's tile: the scalar load has a whole tile to land
+                    } else {
+                        stage_tile<AT, BM, GATHER == 1>(st, A, lda, m0, M, k0, kend, wave, lane, zero, arow);
+                        stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+                    }
                 }
                 const char* sa = smem + cur * STAGE_BYTES;
                 const char* sb = sa + A_BYTES;
@@ -380,6 +433,14 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
             const int n = n0 + c8;
             const bool ncol = n < N;
             bf16x8 hx[PASSES];
+            int crow[PASSES];                          // GATHER 1: storage rows of this thread's output rows, loaded together
+            if constexpr (GATHER == 1) {
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps) {
+                    const int m = mh + rr + RPP * ps;
+                    crow[ps] = e.rowmap[m < M ? m : M - 1];
+                }
+            }
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             constexpr bool CS = (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_MUL_GELU_GRAD);
             if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
@@ -396,7 +457,9 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                 const int r = rr + RPP * ps, m = mh + r;
                 if (!(ncol && m < M)) continue;
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CP + c8 * 2);
-                const long off = (long)m * e.ldc + n;
+                long orow = m;
+                if constexpr (GATHER == 1) orow = crow[ps];
+                const long off = orow * e.ldc + n;
                 if constexpr (EPI == WJ_EPI_BF16) {
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = v;
                     if (e.colsum) {
@@ -473,7 +536,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     }
 }
 
-template <bool AT, bool BT, int EPI, int BN, bool STAGGER>
+template <bool AT, bool BT, int EPI, int BN, bool STAGGER, int GATHER = 0>
 int launch(const wj_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     int split = a->split_k < 1 ? 1 : a->split_k;
@@ -483,7 +546,8 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     e.C = a->C; e.C2 = a->epilogue == WJ_EPI_BIAS_GELU ? nullptr : a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc; e.colsum = a->colsum;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
-    auto kern = gemm3_kernel<AT, BT, EPI, BN, STAGGER>;
+    e.rowmap = a->rowmap;
+    auto kern = gemm3_kernel<AT, BT, EPI, BN, STAGGER, GATHER>;
     constexpr int lds = Cfg<BN>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
@@ -544,9 +608,16 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD && !a->aux) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
     if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->rowmap) {
+        // gather forms (sparse conv backward), one instantiation each
+        if (!a->a_trans && a->b_trans && a->epilogue == WJ_EPI_BF16 && !a->colsum && !a->bias)
+            return launch<false, true, WJ_EPI_BF16, 128, false, 1>(a, s);
+        if (a->a_trans && a->b_trans && a->epilogue == WJ_EPI_ATOMIC_F32) return launch<true, true, WJ_EPI_ATOMIC_F32, 256, false, 2>(a, s);
+        return WJ_ERR_UNSUPPORTED;
+    }
     static const bool use_v1 = getenv("WJ_GEMM_V1") != nullptr;
     if (use_v1) return wj_gemm_bf16_v1(a, stream);
-    hipStream_t s = (hipStream_t)stream;
     if (!a->a_trans && !a->b_trans) return dispatch_epi<false, false>(a, s);
     if (!a->a_trans && a->b_trans) return dispatch_epi<false, true>(a, s);
     if (a->a_trans && a->b_trans) return dispatch_epi<true, true>(a, s);

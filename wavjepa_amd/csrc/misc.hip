@@ -26,6 +26,34 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
     }
 }
 
+// listed rows only (sparse conv backward); the consumed dpost rows are zeroed on the way (clear_dpost) so that the buffer
+// is all-zero again for the next step
+__global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(bf16_t* __restrict__ dpost, const bf16_t* __restrict__ pre,
+                                                            bf16_t* __restrict__ dpre, const int32_t* __restrict__ rows,
+                                                            int n_rows, int row8, int clear_dpost) {
+    const long n8 = (long)n_rows * row8;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / row8), c = (int)(i - (long)r * row8);
+        const long off = ((long)rows[r] * row8 + c) * 8;
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dpost + off);
+        const bf16x8 p = *reinterpret_cast<const bf16x8*>(pre + off);
+        bf16x8 o, z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = f2bf(bf2f(d[e]) * gelu_grad_f(bf2f(p[e]))); z[e] = f2bf(0.f); }
+        *reinterpret_cast<bf16x8*>(dpre + off) = o;
+        if (clear_dpost) *reinterpret_cast<bf16x8*>(dpost + off) = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_rows_kernel(char* __restrict__ buf, const int32_t* __restrict__ rows, int n_rows,
+                                                        int row16) {
+    const long n = (long)n_rows * row16;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / row16), c = (int)(i - (long)r * row16);
+        *reinterpret_cast<uint4*>(buf + ((long)rows[r] * row16 + c) * 16) = make_uint4(0, 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- conv weight layouts
 __global__ __launch_bounds__(256) void conv_w_kernel(wj_conv_w_args a) {
     const int Co = a.C_out, Ci = a.C_in, k = a.k;
@@ -437,15 +465,33 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_attn_bwd_args) WJ_SZ(wj_conv0_fwd_args) WJ_SZ(wj_conv0_bwd_args) WJ_SZ(wj_gelu_bwd_args) WJ_SZ(wj_conv_w_args)
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
-    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args)
+    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args)
 #undef WJ_SZ
     return -1;
 }
 
 extern "C" int wj_gelu_bwd_bf16(const wj_gelu_bwd_args* a, void* stream) {
+    if (a && a->rows) {
+        if (!a->dpost || !a->pre || !a->dpre || a->n_rows < 0 || a->row_elems <= 0 || (a->row_elems & 7)) return WJ_ERR_ARG;
+        if (a->n_rows == 0) return WJ_OK;
+        hipLaunchKernelGGL(gelu_bwd_rows_kernel, dim3(grid_for((long)a->n_rows * (a->row_elems / 8), 256)), dim3(256), 0, STREAM,
+                           (bf16_t*)a->dpost, (const bf16_t*)a->pre, (bf16_t*)a->dpre, a->rows, a->n_rows, a->row_elems / 8,
+                           a->clear_dpost);
+        WJ_CHECK_LAUNCH();
+        return WJ_OK;
+    }
     if (!a || !a->dpost || !a->pre || !a->dpre || a->n <= 0 || (a->n & 7)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(a->n / 8, 256)), dim3(256), 0, STREAM, (const bf16_t*)a->dpost,
                        (const bf16_t*)a->pre, (bf16_t*)a->dpre, (long)(a->n / 8));
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_zero_rows(const wj_zero_rows_args* a, void* stream) {
+    if (!a || !a->buf || !a->rows || a->n_rows < 0 || a->row_bytes <= 0 || (a->row_bytes & 15)) return WJ_ERR_ARG;
+    if (a->n_rows == 0) return WJ_OK;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long)a->n_rows * (a->row_bytes / 16), 256)), dim3(256), 0, STREAM,
+                       (char*)a->buf, a->rows, a->n_rows, a->row_bytes / 16);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

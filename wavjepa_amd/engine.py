@@ -60,6 +60,7 @@ class MaskPlan:
     max_enc: int = 0                          # longest context / visible sequence (attention length bound)
     max_dec: int = 0
     ragged_ok: bool = False                   # False when a target position is key-masked: the dense path must be used
+    ctx_np: Optional[np.ndarray] = None       # host copy of the context mask (True = NOT context), for the conv row lists
 
 
 def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
@@ -93,7 +94,7 @@ def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
                     int(keep_np.size), enc_off=up(enc_off, np.int32), dec_rows=up(dec_rows, np.int32),
                     dec_off=up(dec_off, np.int32), dec_map=up(dec_map, np.int32), n_dec=int(dec_rows.size),
                     max_enc=int(ctx_len.max()) if ctx_len.size else 0, max_dec=int(dec_len.max()) if dec_len.size else 0,
-                    ragged_ok=ragged_ok)
+                    ragged_ok=ragged_ok, ctx_np=ctx_np)
 
 
 def conv_geometry(n_samples: int, spec) -> Tuple[List[int], List[int]]:
@@ -114,6 +115,43 @@ def conv_geometry(n_samples: int, spec) -> Tuple[List[int], List[int]]:
         if all(P[l] >= L[l] + need[l] for l in range(n)):
             return L, P
         p_last += 1
+
+
+def conv_active_rows(keep: np.ndarray, P: Sequence[int], spec) -> Dict[int, Tuple[np.ndarray, np.ndarray]]:
+    """Rows of every conv layer's output that can carry a gradient when only `keep` [N, T] (bool) rows of the LAST layer's
+    output do (the student sees the context tokens only, so ~80 % of the conv backward would multiply zeros).
+
+    Returns {l: (act, ext)} of int32 GLOBAL row indices (clip * P[l] + row), ascending:
+      act[l]: rows of layer l's output gradient that are written this step (consumed by GELU', wgrad, and cleared after);
+      ext[l]: act[l] grown by the dgrad halo (ceil(k/s) - 1 rows after every run): the logical rows of the dgrad GEMM, whose
+              outputs s*g + rho, rho < s, are exactly act[l-1].
+    Only act is returned for layer 0 (ext[0] is None)."""
+    N, T = keep.shape
+    edge = np.diff(np.concatenate([np.zeros((N, 1), np.int8), keep.astype(np.int8), np.zeros((N, 1), np.int8)], axis=1), axis=1)
+    clip, start = np.nonzero(edge == 1)
+    _, end = np.nonzero(edge == -1)          # same (clip, position) order: the i-th end closes the i-th start
+
+    def expand(clip, start, end, rows_per_clip):
+        n = end - start
+        if n.size == 0:
+            return np.zeros(0, np.int32)
+        first = np.cumsum(n) - n
+        return (np.repeat(clip.astype(np.int64) * rows_per_clip + start - first, n) + np.arange(int(n.sum()))).astype(np.int32)
+
+    out: Dict[int, Tuple[np.ndarray, Optional[np.ndarray]]] = {}
+    for l in range(len(spec) - 1, 0, -1):
+        _, k, s = spec[l]
+        act = expand(clip, start, end, P[l])
+        grown = end + (-(-k // s) - 1)
+        if start.size:                       # merge runs that now touch or overlap inside a clip
+            new = np.ones(start.size, bool)
+            new[1:] = (clip[1:] != clip[:-1]) | (start[1:] > grown[:-1])
+            head = np.flatnonzero(new)
+            clip, start, grown = clip[head], start[head], np.maximum.reduceat(grown, head)
+        out[l] = (act, expand(clip, start, grown, P[l]))
+        start, end = start * s, grown * s
+    out[0] = (expand(clip, start, end, P[0]), None)
+    return out
 
 
 class _Layer:
@@ -165,6 +203,9 @@ class JepaEngine:
         # key-masked shapes (identical loss and gradients, ~2x the work)
         self.ragged = _os.environ.get("WJ_RAGGED", "1") != "0"
         self.ragged_step = False
+        # conv backward over the active rows only (needs a ragged step and k >= stride in every GEMM conv layer)
+        self.sparse_conv = _os.environ.get("WJ_SPARSE_CONV", "1") != "0" and all(k >= st for _, k, st in cfg.conv_spec[1:])
+        self._conv_grads_dirty = False
         self.side = torch.cuda.Stream(device=self.dev)
         self._ev = [torch.cuda.Event() for _ in range(8)]
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
@@ -433,6 +474,8 @@ class JepaEngine:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
         self._on_side(self._teacher_targets)
         self.ragged_step = self.ragged and plan.ragged_ok
+        if self.ragged_step and self.sparse_conv and torch.is_grad_enabled():
+            self._conv_rows(plan)       # host-side list building + upload, hidden behind the forward kernels already queued
         n_ctx = plan.n_ctx
         if self.ragged_step:
             # student encoder on the context rows only, packed per clip (non-context rows are dropped at jepa.py:399 and,
@@ -589,14 +632,32 @@ class JepaEngine:
         ops.layernorm_bwd(d_fn, self.post_ptr[-1], f.ptr32("feature_norms.weight"), self.fn_mean, self.fn_rstd, M=M, D=C,
                           ds_bf16=self.dpost_ptr[-1], dgamma=f.gptr("feature_norms.weight"), dbeta=f.gptr("feature_norms.bias"),
                           x_is_bf16=True, in_seg=self.P[-1], in_valid=T, out_seg=self.P[-1], out_valid=T)
+        sparse = rag and self.sparse_conv
+        if sparse:
+            act_rows = self._conv_rows(plan)
+            if self._conv_grads_dirty:       # a dense step left gradients everywhere: restore the all-zero state once
+                for t in self.dpost + self.dpre[1:]:
+                    t.zero_()
+                self._conv_grads_dirty = False
+        else:
+            self._conv_grads_dirty = True
         for l in range(nl - 1, 0, -1):
             _, k, s = c.conv_spec[l]
             rows = N * self.P[l]
-            ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], rows * C)
             dwp = self._conv_w[f"dwp{l}"]
             dwp.zero_()
-            ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=rows, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
-                     b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, rows))
+            if sparse:
+                # Only act[l] rows of this layer's output gradient are non-zero.  Every gradient buffer is all-zero outside
+                # the rows written this step (they are cleared again below), so the dgrad taps may read neighbours freely.
+                act, n_act, ext, n_ext = act_rows[l]
+                ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], 0, rows=act, n_rows=n_act, row_elems=C,
+                                  clear_dpost=l < nl - 1)
+                ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=n_act, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
+                         b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, n_act), rowmap=act)
+            else:
+                ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], rows * C)
+                ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=rows, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
+                         b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, rows))
             ops.conv_weight_layout(dwp, f.gptr(f"extract_audio.cnn.{l}.0.weight"), C_out=C, C_in=C, k=k, mode=2)
             empty_phase = any(len(range(rho, k, s)) == 0 for rho in range(s))
             if empty_phase:
@@ -605,19 +666,45 @@ class JepaEngine:
                 U = len(range(rho, k, s))
                 if U == 0:
                     continue
-                ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
-                         M=rows, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1)
+                if sparse:
+                    ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
+                             M=n_ext, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1, rowmap=ext)
+                else:
+                    ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
+                             M=rows, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1)
+            if sparse:
+                ops.zero_rows(self.dpre_ptr[l], act, n_rows=n_act, row_bytes=C * 2)
         _, k0, s0 = c.conv_spec[0]
         ops.conv0_bwd(self.audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
                       f.ptr32("extract_audio.cnn.0.2.bias"), self.gn_stats[0], self.gn_stats[1], self.dpost_ptr[0],
                       f.gptr("extract_audio.cnn.0.0.weight"), f.gptr("extract_audio.cnn.0.2.weight"),
                       f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws, N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0,
                       stride=s0, L_out=self.L[0], P=self.P[0])
+        if sparse:
+            act, n_act, _, _ = act_rows[0]
+            ops.zero_rows(self.dpost_ptr[0], act, n_rows=n_act, row_bytes=C * 2)
         self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
         for tag in ("enc", "dec"):
             self.bw[tag]["used"] = [False, False]
         if on_grads_ready is not None:
             on_grads_ready("front")
+
+    def _conv_rows(self, plan: MaskPlan):
+        """Device copies of conv_active_rows for this plan (cached on the plan: mask sets are reused by the data source)."""
+        cached = getattr(plan, "_conv_rows", None)
+        if cached is not None and cached[0] == (self.N, tuple(self.P)):
+            return cached[1]
+        keep = (plan.ctx_u8.cpu().numpy() == 0) if plan.ctx_np is None else ~plan.ctx_np
+        lists = conv_active_rows(keep, self.P, self.cfg.conv_spec)
+        pad = np.zeros(256, np.int32)        # the k-gather GEMM prefetches indices up to 256 entries past the end
+
+        def up(a):
+            return torch.from_numpy(np.concatenate([a, pad])).to(self.dev, non_blocking=True)
+
+        out = {l: (up(act), int(act.size), None if ext is None else up(ext), 0 if ext is None else int(ext.size))
+               for l, (act, ext) in lists.items()}
+        plan._conv_rows = ((self.N, tuple(self.P)), out)
+        return out
 
     # ------------------------------------------------------------------------------------------------ EMA / inference
     def ema_step(self, r: float) -> None:

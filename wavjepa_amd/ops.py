@@ -65,8 +65,10 @@ def require_gpu() -> None:
 # ---------------------------------------------------------------------------------------------------------- GEMM
 def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, a_trans: int = 0,
          b_trans: int = 0, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, aux: Ptr = None, split_k: int = 1,
-         seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, colsum: Ptr = None, stream: Optional[int] = None) -> None:
+         seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, colsum: Ptr = None, rowmap: Ptr = None,
+         stream: Optional[int] = None) -> None:
     _run("wj_gemm_bf16", "wj_gemm_args", stream, A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), aux=_p(aux), colsum=_p(colsum),
+         rowmap=_p(rowmap),
          lda=lda, ldb=ldb, ldc=ldc, M=M, N=N, K=K, a_trans=a_trans, b_trans=b_trans, epilogue=epilogue, split_k=split_k,
          seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
 
@@ -139,8 +141,15 @@ def conv0_bwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, mean: Ptr, rstd: Ptr, d
          N=N, C_in=C_in, L=L, C=C, k=k, stride=stride, L_out=L_out, P=P)
 
 
-def gelu_bwd_bf16(dpost: Ptr, pre: Ptr, dpre: Ptr, n: int, stream: Optional[int] = None) -> None:
-    _run("wj_gelu_bwd_bf16", "wj_gelu_bwd_args", stream, dpost=_p(dpost), pre=_p(pre), dpre=_p(dpre), n=n)
+def gelu_bwd_bf16(dpost: Ptr, pre: Ptr, dpre: Ptr, n: int, *, rows: Ptr = None, n_rows: int = 0, row_elems: int = 0,
+                  clear_dpost: bool = False, stream: Optional[int] = None) -> None:
+    """rows (int32 [n_rows]) selects the listed-rows form over [.][row_elems] matrices."""
+    _run("wj_gelu_bwd_bf16", "wj_gelu_bwd_args", stream, dpost=_p(dpost), pre=_p(pre), dpre=_p(dpre), rows=_p(rows), n=n,
+         n_rows=n_rows, row_elems=row_elems, clear_dpost=int(clear_dpost))
+
+
+def zero_rows(buf: Ptr, rows: Ptr, *, n_rows: int, row_bytes: int, stream: Optional[int] = None) -> None:
+    _run("wj_zero_rows", "wj_zero_rows_args", stream, buf=_p(buf), rows=_p(rows), n_rows=n_rows, row_bytes=row_bytes)
 
 
 def conv_weight_layout(src: Ptr, dst: Ptr, *, C_out: int, C_in: int, k: int, mode: int, stride: int = 1, rho: int = 0,
