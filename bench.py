@@ -68,17 +68,21 @@ def profile_one_step(runner, source, step_idx: int):
     finally:
         ops.PROFILE = None
         eng.use_side = side
-    classes = {}
+    classes, shapes = {}, {}
     for fn, f, e0, e1 in recs:
         ms = e0.elapsed_time(e1)
         if fn == "wj_gemm_bf16":
             name, flops = gemm_kernel_name(f), 2.0 * f["M"] * f["N"] * f["K"]
+            key = f"{name} M={f['M']} N={f['N']} K={f['K']}" + (" gather" if f.get("rowmap") else "")
+            sh = shapes.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
+            sh["ms"] += ms; sh["flops"] += flops; sh["launches"] += 1
         else:
             name, flops = fn, 0.0
         c = classes.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
         c["ms"] += ms
         c["flops"] += flops
         c["launches"] += 1
+    profile_one_step.shapes = shapes
     return classes
 
 
@@ -238,6 +242,10 @@ def main():
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_classes.json"), "w") as fh:
                 json.dump({k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None) for k, v in top}, fh, indent=1)
+            shapes = sorted(getattr(profile_one_step, "shapes", {}).items(), key=lambda kv: -kv[1]["ms"])
+            with open(os.path.join(ROOT, "gpurun_out", "bench_gemm_shapes.json"), "w") as fh:
+                json.dump({k: dict(ms=round(v["ms"], 3), launches=v["launches"], us_per_launch=round(v["ms"] / v["launches"] * 1e3, 1),
+                                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in shapes}, fh, indent=1)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -184,13 +184,18 @@ typedef struct {
     float* mean;
     float* rstd;
     float* workspace; /* f32 [N][C][2] scratch (sum, sum of squares) */
+    float* yx;        /* optional f32 [N][C][C_in*k]: sum_t y_t x_{t,q}  (kept for the backward; NULL on inference)  */
+    float* x1;        /* optional f32 [N][C_in*k]:    sum_t x_{t,q}      (both or neither)                            */
     int32_t N, C_in, L, C, k, stride, L_out, P;
     float eps;
 } wj_conv0_fwd_args;
 int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args*, void* stream);
 
 /* Backward: dact bf16 [N][P][C] -> dw f32 [C][C_in][k], dgamma, dbeta (all atomically accumulated).
- * workspace: f32 [N][C][2]. */
+ * GroupNorm spreads the gradient over the whole time axis, but that part only needs the forward's yx / x1 sums (see
+ * csrc/conv0.hip); dact itself is read on the LISTED rows only: rows = int32 global row indices (n*P + t, ascending,
+ * grouped by clip), row_off = int32 [N+1] offsets of every clip's rows, max_rows = the longest clip list.  rows == NULL
+ * reads every row t < L_out.  workspace: f32 [N][C][2 + C_in*k]. */
 typedef struct {
     const void* audio;
     const void* w;
@@ -199,11 +204,16 @@ typedef struct {
     const float* mean;
     const float* rstd;
     const void* dact;
+    const float* yx;
+    const float* x1;
+    const int32_t* rows;
+    const int32_t* row_off;
     float* dw;
     float* dgamma;
     float* dbeta;
     float* workspace;
     int32_t N, C_in, L, C, k, stride, L_out, P;
+    int32_t max_rows;
 } wj_conv0_bwd_args;
 int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args*, void* stream);
 

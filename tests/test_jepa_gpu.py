@@ -169,7 +169,7 @@ def test_sparse_conv_backward_equals_dense_across_steps(golden_dir):
     sets = [tuple(torch.from_numpy(fx[k][i:i + 3]) for k in ("as_ctx", "as_tgt", "as_vis")) for i in (0, 3)]
     audios = [torch.from_numpy(synth.synth_audio(3, 1, 32159, seed=11 + i)).to(torch.bfloat16).to(dev()) for i in range(2)]
     grads = {}
-    for sparse in (True, False):
+    for tag, sparse in (("sparse", True), ("dense", False), ("dense2", False)):
         m, _ = build(SMALL)
         eng = m._ensure_engine()
         eng.sparse_conv = sparse
@@ -178,10 +178,17 @@ def test_sparse_conv_backward_equals_dense_across_steps(golden_dir):
             out = m(audios[i], *sets[i])
             out["loss"].backward()
         assert eng.ragged_step
-        grads[sparse] = {k: p.grad.double().clone() for k, p in m.named_parameters() if k.startswith(("extract_audio", "feature_norms"))}
-    for k, want in grads[False].items():
-        err = float((grads[True][k] - want).norm() / (want.norm() + 1e-30))
-        assert err < 5e-3, (k, err)
+        grads[tag] = {k: p.grad.double().clone() for k, p in m.named_parameters() if k.startswith(("extract_audio", "feature_norms"))}
+
+    def err(a, b):
+        return {k: float((grads[a][k] - grads[b][k]).norm() / (grads[b][k].norm() + 1e-30)) for k in grads[b]}
+
+    # the fp32 atomics upstream (split-K wgrad, bias sums) make two identical runs differ by bf16 rounding flips that grow
+    # down the conv stack: the yardstick for "equal" is the dense run-to-run noise
+    noise, got = err("dense2", "dense"), err("sparse", "dense")
+    print("conv backward rel err per tensor, dense vs dense:", noise, "sparse vs dense:", got)
+    for k in got:
+        assert got[k] < max(3.0 * noise[k], 2e-3), (k, got[k], noise[k])
 
 
 def test_target_outside_visible_set_falls_back_to_dense(golden_dir):

@@ -388,7 +388,10 @@ def test_conv0_fwd_bwd(ops, N, C_in, L, C):
     act = torch.empty(N, P, C, dtype=torch.bfloat16, device=dev())
     stats = torch.empty(2, N, C, device=dev())
     ws = torch.empty(N, C, 2, device=dev())
-    ops.conv0_fwd(audio, wb, gamma, beta, act, stats[0], stats[1], ws, N=N, C_in=C_in, L=L, C=C, k=k, stride=s, L_out=L_out, P=P)
+    yx = torch.empty(N, C, C_in * k, device=dev())
+    x1 = torch.empty(N, C_in * k, device=dev())
+    ops.conv0_fwd(audio, wb, gamma, beta, act, stats[0], stats[1], ws, N=N, C_in=C_in, L=L, C=C, k=k, stride=s, L_out=L_out, P=P,
+                  yx=yx, x1=x1)
     wr = wb.float().requires_grad_(True)
     gr = gamma.clone().requires_grad_(True)
     br = beta.clone().requires_grad_(True)
@@ -407,12 +410,42 @@ def test_conv0_fwd_bwd(ops, N, C_in, L, C):
     dw = torch.zeros(C, C_in, k, device=dev())
     dg = torch.zeros(C, device=dev())
     db = torch.zeros(C, device=dev())
-    ws2 = torch.empty(N, C, 2, device=dev())
-    ops.conv0_bwd(audio, wb, gamma, beta, stats[0], stats[1], dact, dw, dg, db, ws2, N=N, C_in=C_in, L=L, C=C, k=k, stride=s,
-                  L_out=L_out, P=P)
+    ws2 = torch.empty(N, C, 2 + C_in * k, device=dev())
+    ops.conv0_bwd(audio, wb, gamma, beta, stats[0], stats[1], dact, dw, dg, db, ws2, yx=yx, x1=x1, N=N, C_in=C_in, L=L, C=C, k=k,
+                  stride=s, L_out=L_out, P=P)
     assert relerr(dg, gr.grad) < 5e-3
     assert relerr(db, br.grad) < 5e-3
     assert relerr(dw, wr.grad) < 1e-2
+    # forward sums kept for the backward: patches x_{t,q} = audio[ci][s t + kk], q = ci*k + kk
+    patches = audio.float().unfold(2, k, s).permute(0, 2, 1, 3).reshape(N, L_out, C_in * k)
+    assert relerr(x1, patches.sum(1)) < 1e-4 or maxerr(x1, patches.sum(1)) < 1e-2
+    assert relerr(yx, torch.einsum("nct,ntq->ncq", y.detach(), patches)) < 1e-3
+    # listed-rows form: the output gradient is zero outside a few runs of rows (the student's context) and only those
+    # rows are read -- GroupNorm still spreads the gradient over the whole time axis through the forward sums
+    g = torch.Generator().manual_seed(45)
+    live = torch.zeros(N, L_out, dtype=torch.bool)
+    for n in range(N):
+        for st in torch.randint(0, L_out - 40, (5,), generator=g).tolist():
+            live[n, st:st + 37] = True
+    live[N - 1] = False
+    live[N - 1, 5] = True                                          # a clip with a single live row
+    dact2 = torch.zeros_like(dact)
+    dact2[:, :L_out][live.to(dev())] = dact[:, :L_out][live.to(dev())]
+    rows = torch.nonzero(torch.cat([live, torch.zeros(N, P - L_out, dtype=torch.bool)], 1).reshape(-1)).squeeze(1).to(torch.int32)
+    off = torch.zeros(N + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(live.sum(1), 0).to(torch.int32)
+    for t in (wr, gr, br):
+        t.grad = None
+    y = F.conv1d(audio.float(), wr, stride=s).to(torch.bfloat16).float()
+    y_ste = F.conv1d(audio.float(), wr, stride=s)
+    F.gelu(F.group_norm(y_ste + (y - y_ste).detach(), C, gr, br, 1e-5)).transpose(1, 2).backward(dact2[:, :L_out].float())
+    dw2, dg2, db2 = torch.zeros_like(dw), torch.zeros_like(dg), torch.zeros_like(db)
+    poison = dact2.clone()
+    poison[:, :L_out][~live.to(dev())] = 1e4                       # rows outside the list must never be read
+    ops.conv0_bwd(audio, wb, gamma, beta, stats[0], stats[1], poison, dw2, dg2, db2, ws2, yx=yx, x1=x1, N=N, C_in=C_in, L=L, C=C,
+                  k=k, stride=s, L_out=L_out, P=P, rows=rows.to(dev()), row_off=off.to(dev()), max_rows=int(live.sum(1).max()))
+    assert relerr(dg2, gr.grad) < 5e-3 and relerr(db2, br.grad) < 5e-3
+    assert relerr(dw2, wr.grad) < 1e-2
 
 
 def test_gelu_bwd_and_conv_weight_layouts(ops):

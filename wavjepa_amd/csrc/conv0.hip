@@ -3,6 +3,14 @@
 // [N][P][C] channels-last bf16 activation (1.69 GB at N=256), written exactly once.  The conv is recomputed from
 // the audio wherever it is needed (statistics pass, apply pass, both backward passes) instead of being stored.
 //   thread = 4 consecutive channels x one time parity;  a wave stores 512 contiguous bytes per time step.
+//
+// Backward.  With dz_t = dact_t gelu'(z_t), A1 = sum_t dz_t, A2 = sum_t dz_t xh_t, GroupNorm gives
+//   dy_t = rstd gamma (dz_t - A1/L - xh_t A2/L)   for EVERY t, and   dw[c][q] = sum_n sum_t dy_t x_{t,q}.
+// Splitting the sum,  dw = sum_n rstd gamma [ S - (A1/L) X1 - (A2/L) rstd (YX - mean X1) ]  with
+//   S[q]  = sum_t dz_t x_{t,q}      only rows with a non-zero output gradient contribute (the student's context: ~20 %),
+//   X1[q] = sum_t x_{t,q},  YX[q] = sum_t y_t x_{t,q}      gradient-independent: accumulated by the FORWARD statistics pass.
+// So the backward is ONE pass over the listed active rows (A1, A2, S) plus a tiny per-(n,c) finalize; the dense part of
+// GroupNorm's backward never touches the activation-sized tensors.
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
 
@@ -55,11 +63,14 @@ __device__ __forceinline__ void conv4(float (&y)[4], float (&x)[TAPS], const flo
     }
 }
 
-// ---- pass 1 (forward): per-(n,c) sum and sum of squares of the bf16-rounded conv output -------------------
+// ---- pass 1 (forward): per-(n,c) sum and sum of squares of the bf16-rounded conv output; when yx != NULL also
+//      YX[n][c][q] = sum_t y_t x_{t,q} and X1[n][q] = sum_t x_{t,q} (what the backward needs of the dense time axis)
 template <int TAPS>
 __global__ __launch_bounds__(NTH) void conv0_stats_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
-                                                          float* __restrict__ sums, Geo g, int span_max) {
+                                                          float* __restrict__ sums, float* __restrict__ yx,
+                                                          float* __restrict__ x1, Geo g, int span_max) {
     extern __shared__ float xs[];
+    float* red = xs + g.C_in * span_max;  // [4*TAPS][128] partials of the odd-time half (yx only)
     const int n = blockIdx.y, t0 = blockIdx.x * TC;
     const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
     stage_audio(xs, audio, g, n, t0, span_max);
@@ -67,10 +78,18 @@ __global__ __launch_bounds__(NTH) void conv0_stats_kernel(const bf16_t* __restri
     const int tmax = min(TC, g.L_out - t0);
     for (int cb = 0; cb < g.C; cb += 512) {
         const int c4 = cb + cl * 4;
-        if (c4 < g.C) {
+        const bool live = c4 < g.C;
+        float acc[4][TAPS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = 0.f;
+        if (live) {
             float w[4][TAPS];
             load_weights<TAPS>(w, wsrc, c4);
-            float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+            float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, xsum[TAPS];
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) xsum[tp] = 0.f;
             int off[TAPS];
             tap_offsets<TAPS>(off, g, span_max);
             for (int tl = half; tl < tmax; tl += 2) {
@@ -78,11 +97,42 @@ __global__ __launch_bounds__(NTH) void conv0_stats_kernel(const bf16_t* __restri
                 conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s1[j] += y[j]; s2[j] += y[j] * y[j]; }
+                if (yx) {                                   // kernel-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = fmaf(y[j], x[tp], acc[j][tp]);
+                    if (cb == 0 && cl == 0) {
+#pragma unroll
+                        for (int tp = 0; tp < TAPS; ++tp) xsum[tp] += x[tp];
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 atomicAdd(sums + ((long)n * g.C + c4 + j) * 2 + 0, s1[j]);
                 atomicAdd(sums + ((long)n * g.C + c4 + j) * 2 + 1, s2[j]);
+            }
+            if (yx && cb == 0 && cl == 0) {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) atomicAdd(x1 + (long)n * TAPS + tp, xsum[tp]);
+            }
+        }
+        if (yx) {                                           // fold the two time-parity halves, one atomic per (c, q)
+            __syncthreads();
+            if (live && half == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tp = 0; tp < TAPS; ++tp) red[(j * TAPS + tp) * 128 + cl] = acc[j][tp];
+            }
+            __syncthreads();
+            if (live && half == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tp = 0; tp < TAPS; ++tp)
+                        atomicAdd(yx + ((long)n * g.C + c4 + j) * TAPS + tp, acc[j][tp] + red[(j * TAPS + tp) * 128 + cl]);
             }
         }
     }
@@ -140,73 +190,37 @@ __global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restri
     }
 }
 
-// ---- backward pass 1: A1 = sum_t dz, A2 = sum_t dz * xhat per (n,c) ----------------------------------------------
+// ---- backward, pass over the listed rows: A1 = sum dz, A2 = sum dz xh, S[q] = sum dz x_q  per (n, c) ------------------
+// ws: f32 [N][C][2 + TAPS].  rows == NULL: every row t < L_out of every clip.  Workgroup = (chunk of BR listed rows, clip).
+constexpr int BR = 256;
 template <int TAPS>
-__global__ __launch_bounds__(NTH) void conv0_bwd_stats_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const bf16_t* __restrict__ dact, float* __restrict__ ws, Geo g,
-                                                              int span_max) {
-    extern __shared__ float xs[];
-    const int n = blockIdx.y, t0 = blockIdx.x * TC;
+__global__ __launch_bounds__(NTH) void conv0_bwd_rows_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const bf16_t* __restrict__ dact, const int32_t* __restrict__ rows,
+                                                             const int32_t* __restrict__ row_off, float* __restrict__ ws, Geo g) {
+    extern __shared__ float xs[];                      // [BR][TAPS] audio patches of this chunk's rows
+    int* tl = reinterpret_cast<int*>(xs + BR * TAPS);  // [BR] their time steps
+    float* red = xs + BR * TAPS + BR;                  // [(2 + TAPS) * 4][128] partials of the odd half
+    const int n = blockIdx.y;
+    const int first = rows ? row_off[n] : 0;
+    const int cnt = rows ? row_off[n + 1] - first : g.L_out;
+    const int j0 = blockIdx.x * BR;
+    if (j0 >= cnt) return;
+    const int jn = min(BR, cnt - j0);
     const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
-    stage_audio(xs, audio, g, n, t0, span_max);
+    for (int j = threadIdx.x; j < jn; j += NTH) tl[j] = rows ? rows[first + j0 + j] - n * g.P : j0 + j;
     __syncthreads();
-    const int tmax = min(TC, g.L_out - t0);
-    for (int cb = 0; cb < g.C; cb += 512) {
-        const int c4 = cb + cl * 4;
-        if (c4 >= g.C) continue;
-        float w[4][TAPS];
-        load_weights<TAPS>(w, wsrc, c4);
-        float mu[4], rs[4], ga[4], be[4], a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mu[j] = mean[(long)n * g.C + c4 + j]; rs[j] = rstd[(long)n * g.C + c4 + j];
-            ga[j] = gamma[c4 + j]; be[j] = beta[c4 + j];
-        }
-        int off[TAPS];
-        tap_offsets<TAPS>(off, g, span_max);
-        for (int tl = half; tl < tmax; tl += 2) {
-            const int t = t0 + tl;
-            float y[4], x[TAPS];
-            conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
-            const bf16x4 d = *reinterpret_cast<const bf16x4*>(dact + ((long)n * g.P + t) * g.C + c4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xh = (y[j] - mu[j]) * rs[j];
-                const float dz = bf2f(d[j]) * gelu_grad_f(xh * ga[j] + be[j]);
-                a1[j] += dz;
-                a2[j] += dz * xh;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            atomicAdd(ws + ((long)n * g.C + c4 + j) * 2 + 0, a1[j]);
-            atomicAdd(ws + ((long)n * g.C + c4 + j) * 2 + 1, a2[j]);
-        }
+    for (int idx = threadIdx.x; idx < jn * TAPS; idx += NTH) {
+        const int j = idx / TAPS, tp = idx - j * TAPS;
+        const int ci = tp / g.k, kk = tp - ci * g.k;
+        xs[idx] = bf2f(audio[((long)n * g.C_in + ci) * g.L + (long)tl[j] * g.stride + kk]);
     }
-}
-
-// ---- backward pass 2: dy through GroupNorm, accumulate dw (and dgamma/dbeta once per (n,c)) -----------------------
-template <int TAPS>
-__global__ __launch_bounds__(NTH) void conv0_bwd_apply_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const bf16_t* __restrict__ dact, const float* __restrict__ ws,
-                                                              float* __restrict__ dw, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, Geo g, int span_max) {
-    extern __shared__ float xs[];
-    float* red = xs + g.C_in * span_max;  // [128][4*TAPS] partials of the odd-time half
-    const int n = blockIdx.y, t0 = blockIdx.x * TC;
-    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
-    stage_audio(xs, audio, g, n, t0, span_max);
     __syncthreads();
-    const int tmax = min(TC, g.L_out - t0);
-    const float invL = 1.0f / (float)g.L_out;
     for (int cb = 0; cb < g.C; cb += 512) {
         const int c4 = cb + cl * 4;
         const bool live = c4 < g.C;
-        float acc[4][TAPS];
+        float acc[4][TAPS], a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -214,49 +228,92 @@ __global__ __launch_bounds__(NTH) void conv0_bwd_apply_kernel(const bf16_t* __re
         if (live) {
             float w[4][TAPS];
             load_weights<TAPS>(w, wsrc, c4);
-            float mu[4], rs[4], ga[4], be[4], m1[4], m2[4];
+            float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 mu[j] = mean[(long)n * g.C + c4 + j]; rs[j] = rstd[(long)n * g.C + c4 + j];
                 ga[j] = gamma[c4 + j]; be[j] = beta[c4 + j];
-                const float A1 = ws[((long)n * g.C + c4 + j) * 2], A2 = ws[((long)n * g.C + c4 + j) * 2 + 1];
-                m1[j] = A1 * invL; m2[j] = A2 * invL;
-                if (blockIdx.x == 0 && half == 0) {
-                    atomicAdd(dbeta + c4 + j, A1);
-                    atomicAdd(dgamma + c4 + j, A2);
-                }
             }
-            int off[TAPS];
-            tap_offsets<TAPS>(off, g, span_max);
-            for (int tl = half; tl < tmax; tl += 2) {
-                const int t = t0 + tl;
-                float y[4], x[TAPS];
-                conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
-                const bf16x4 d = *reinterpret_cast<const bf16x4*>(dact + ((long)n * g.P + t) * g.C + c4);
+            for (int jj = half; jj < jn; jj += 2) {
+                float x[TAPS];
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) x[tp] = xs[jj * TAPS + tp];
+                const bf16x4 d = *reinterpret_cast<const bf16x4*>(dact + ((long)n * g.P + tl[jj]) * g.C + c4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xh = (y[j] - mu[j]) * rs[j];
-                    const float dz = bf2f(d[j]) * gelu_grad_f(xh * ga[j] + be[j]);
-                    const float dy = rs[j] * ga[j] * (dz - m1[j] - xh * m2[j]);
+                    float a = 0.f;
 #pragma unroll
-                    for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = fmaf(dy, x[tp], acc[j][tp]);
+                    for (int tp = 0; tp < TAPS; ++tp) a = fmaf(x[tp], w[j][tp], a);
+                    const float y = bf2f(f2bf(a));
+                    const float xh = (y - mu[j]) * rs[j];
+                    const float dz = bf2f(d[j]) * gelu_grad_f(xh * ga[j] + be[j]);
+                    a1[j] += dz;
+                    a2[j] = fmaf(dz, xh, a2[j]);
+#pragma unroll
+                    for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = fmaf(dz, x[tp], acc[j][tp]);
                 }
             }
         }
         __syncthreads();
         if (live && half == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                red[(j * (2 + TAPS) + 0) * 128 + cl] = a1[j];
+                red[(j * (2 + TAPS) + 1) * 128 + cl] = a2[j];
 #pragma unroll
-                for (int tp = 0; tp < TAPS; ++tp) red[(j * TAPS + tp) * 128 + cl] = acc[j][tp];
+                for (int tp = 0; tp < TAPS; ++tp) red[(j * (2 + TAPS) + 2 + tp) * 128 + cl] = acc[j][tp];
+            }
         }
         __syncthreads();
         if (live && half == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                float* o = ws + ((long)n * g.C + c4 + j) * (2 + TAPS);
+                atomicAdd(o + 0, a1[j] + red[(j * (2 + TAPS) + 0) * 128 + cl]);
+                atomicAdd(o + 1, a2[j] + red[(j * (2 + TAPS) + 1) * 128 + cl]);
 #pragma unroll
-                for (int tp = 0; tp < TAPS; ++tp)
-                    atomicAdd(dw + (long)(c4 + j) * TAPS + tp, acc[j][tp] + red[(j * TAPS + tp) * 128 + cl]);
+                for (int tp = 0; tp < TAPS; ++tp) atomicAdd(o + 2 + tp, acc[j][tp] + red[(j * (2 + TAPS) + 2 + tp) * 128 + cl]);
+            }
+        }
+    }
+}
+
+// ---- backward finalize: fold the clips.  Block = 32 (c, q) pairs x 8 clip lanes.
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv0_bwd_final_kernel(const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ ws,
+                                                              const float* __restrict__ yx, const float* __restrict__ x1,
+                                                              float* __restrict__ dw, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, Geo g) {
+    __shared__ float r0[8][33], r1[8][33], r2[8][33];
+    const int pl = threadIdx.x & 31, nl = threadIdx.x >> 5;
+    const int pair = blockIdx.x * 32 + pl;
+    const int c = pair / TAPS, tp = pair - c * TAPS;
+    const bool live = c < g.C;
+    const float invL = 1.0f / (float)g.L_out;
+    float sw = 0.f, sg = 0.f, sb = 0.f;
+    if (live) {
+        const float ga = gamma[c];
+        for (int n = nl; n < g.N; n += 8) {
+            const float* o = ws + ((long)n * g.C + c) * (2 + TAPS);
+            const float A1 = o[0], A2 = o[1], S = o[2 + tp];
+            const float mu = mean[(long)n * g.C + c], rs = rstd[(long)n * g.C + c];
+            const float X1 = x1[(long)n * TAPS + tp], YX = yx[((long)n * g.C + c) * TAPS + tp];
+            sw += rs * ga * (S - A1 * invL * X1 - A2 * invL * rs * (YX - mu * X1));
+            sg += A2;
+            sb += A1;
+        }
+    }
+    r0[nl][pl] = sw; r1[nl][pl] = sg; r2[nl][pl] = sb;
+    __syncthreads();
+    if (nl == 0 && live) {
+        float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += r0[i][pl]; b += r1[i][pl]; d += r2[i][pl]; }
+        atomicAdd(dw + (long)c * TAPS + tp, a);
+        if (tp == 0) {
+            atomicAdd(dgamma + c, b);
+            atomicAdd(dbeta + c, d);
         }
     }
 }
@@ -269,23 +326,26 @@ inline Geo geo_of(int N, int C_in, int L, int C, int k, int stride, int L_out, i
 template <int TAPS>
 void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStream_t s) {
     const size_t lds = (size_t)a->C_in * span_max * sizeof(float);
+    const size_t lds1 = lds + (a->yx ? (size_t)128 * 4 * TAPS * sizeof(float) : 0);
     dim3 grid1((a->L_out + TC - 1) / TC, a->N), grid2((a->P + TC - 1) / TC, a->N), block(NTH);
-    hipLaunchKernelGGL(conv0_stats_kernel<TAPS>, grid1, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
-                       a->workspace, g, span_max);
+    hipLaunchKernelGGL(conv0_stats_kernel<TAPS>, grid1, block, lds1, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
+                       a->workspace, a->yx, a->x1, g, span_max);
     hipLaunchKernelGGL(conv0_apply_kernel<TAPS>, grid2, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
                        a->gamma, a->beta, (const float*)a->workspace, (bf16_t*)a->act, a->mean, a->rstd, g, span_max, a->eps);
 }
 
 template <int TAPS>
-void launch_bwd(const wj_conv0_bwd_args* a, const Geo& g, int span_max, hipStream_t s) {
-    const size_t lds1 = (size_t)a->C_in * span_max * sizeof(float);
-    const size_t lds2 = lds1 + (size_t)128 * 4 * TAPS * sizeof(float);
-    dim3 grid((a->L_out + TC - 1) / TC, a->N), block(NTH);
-    hipLaunchKernelGGL(conv0_bwd_stats_kernel<TAPS>, grid, block, lds1, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
-                       a->gamma, a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, a->workspace, g, span_max);
-    hipLaunchKernelGGL(conv0_bwd_apply_kernel<TAPS>, grid, block, lds2, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
-                       a->gamma, a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, (const float*)a->workspace, a->dw,
-                       a->dgamma, a->dbeta, g, span_max);
+void launch_bwd(const wj_conv0_bwd_args* a, const Geo& g, hipStream_t s) {
+    const size_t lds = (size_t)(BR * TAPS + BR + (2 + TAPS) * 4 * 128) * sizeof(float);
+    const int max_rows = a->rows ? a->max_rows : a->L_out;
+    if (max_rows <= 0) return;
+    static int attr = hipFuncSetAttribute((const void*)conv0_bwd_rows_kernel<TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    dim3 grid((max_rows + BR - 1) / BR, a->N), block(NTH);
+    hipLaunchKernelGGL(conv0_bwd_rows_kernel<TAPS>, grid, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma,
+                       a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, a->rows, a->row_off, a->workspace, g);
+    hipLaunchKernelGGL(conv0_bwd_final_kernel<TAPS>, dim3((a->C * TAPS + 31) / 32), dim3(256), 0, s, a->gamma, a->mean, a->rstd,
+                       (const float*)a->workspace, a->yx, a->x1, a->dw, a->dgamma, a->dbeta, g);
 }
 
 }  // namespace
@@ -297,8 +357,14 @@ extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
     const int span_max = (TC - 1) * a->stride + a->k;
+    if ((a->yx == nullptr) != (a->x1 == nullptr)) return WJ_ERR_ARG;
+    const int taps = a->C_in * a->k;
     if (hipMemsetAsync(a->workspace, 0, sizeof(float) * 2L * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
-    switch (a->C_in * a->k) {
+    if (a->yx) {
+        if (hipMemsetAsync(a->yx, 0, sizeof(float) * (long)a->N * a->C * taps, s) != hipSuccess) return WJ_ERR_LAUNCH;
+        if (hipMemsetAsync(a->x1, 0, sizeof(float) * (long)a->N * taps, s) != hipSuccess) return WJ_ERR_LAUNCH;
+    }
+    switch (taps) {
         case 10: launch_fwd<10>(a, g, span_max, s); break;
         case 20: launch_fwd<20>(a, g, span_max, s); break;
         default: return WJ_ERR_UNSUPPORTED;
@@ -309,16 +375,17 @@ extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
 
 extern "C" int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args* a, void* stream) {
     if (!a || !a->audio || !a->w || !a->gamma || !a->beta || !a->mean || !a->rstd || !a->dact || !a->dw || !a->dgamma ||
-        !a->dbeta || !a->workspace)
+        !a->dbeta || !a->workspace || !a->yx || !a->x1)
         return WJ_ERR_ARG;
     if (a->N <= 0 || a->C <= 0 || (a->C & 3) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
+    if (a->rows && (!a->row_off || a->max_rows < 0)) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
-    const int span_max = (TC - 1) * a->stride + a->k;
-    if (hipMemsetAsync(a->workspace, 0, sizeof(float) * 2L * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
-    switch (a->C_in * a->k) {
-        case 10: launch_bwd<10>(a, g, span_max, s); break;
-        case 20: launch_bwd<20>(a, g, span_max, s); break;
+    const int taps = a->C_in * a->k;
+    if (hipMemsetAsync(a->workspace, 0, sizeof(float) * (2L + taps) * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
+    switch (taps) {
+        case 10: launch_bwd<10>(a, g, s); break;
+        case 20: launch_bwd<20>(a, g, s); break;
         default: return WJ_ERR_UNSUPPORTED;
     }
     WJ_CHECK_LAUNCH();

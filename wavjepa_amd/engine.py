@@ -125,7 +125,7 @@ def conv_active_rows(keep: np.ndarray, P: Sequence[int], spec) -> Dict[int, Tupl
       act[l]: rows of layer l's output gradient that are written this step (consumed by GELU', wgrad, and cleared after);
       ext[l]: act[l] grown by the dgrad halo (ceil(k/s) - 1 rows after every run): the logical rows of the dgrad GEMM, whose
               outputs s*g + rho, rho < s, are exactly act[l-1].
-    Only act is returned for layer 0 (ext[0] is None)."""
+    Layer 0 (no GEMM dgrad below it): (act, per-clip offsets int32 [N+1] into act)."""
     N, T = keep.shape
     edge = np.diff(np.concatenate([np.zeros((N, 1), np.int8), keep.astype(np.int8), np.zeros((N, 1), np.int8)], axis=1), axis=1)
     clip, start = np.nonzero(edge == 1)
@@ -150,7 +150,8 @@ def conv_active_rows(keep: np.ndarray, P: Sequence[int], spec) -> Dict[int, Tupl
             clip, start, grown = clip[head], start[head], np.maximum.reduceat(grown, head)
         out[l] = (act, expand(clip, start, grown, P[l]))
         start, end = start * s, grown * s
-    out[0] = (expand(clip, start, end, P[0]), None)
+    per_clip = np.bincount(clip, weights=end - start, minlength=N).astype(np.int64)
+    out[0] = (expand(clip, start, end, P[0]), np.concatenate([[0], np.cumsum(per_clip)]).astype(np.int32))
     return out
 
 
@@ -304,7 +305,10 @@ class JepaEngine:
                     t, p = self._rows(N * self.P[l], C, bf)
                     self.dpre.append(t); self.dpre_ptr.append(p)
         self.gn_stats = torch.empty(2, N, C, dtype=f32, device=dev)
-        self.gn_ws = torch.empty(N, C, 2, dtype=f32, device=dev)
+        taps = c.in_channels * c.conv_spec[0][1]
+        self.gn_ws = torch.empty(N, C, 2 + taps, dtype=f32, device=dev)
+        self.gn_yx = torch.empty(N, C, taps, dtype=f32, device=dev) if train else None     # forward sums the backward needs
+        self.gn_x1 = torch.empty(N, taps, dtype=f32, device=dev) if train else None
         self.fn_b = torch.empty(M, C, dtype=bf, device=dev)
         self.fn_mean = torch.empty(M, dtype=f32, device=dev)
         self.fn_rstd = torch.empty(M, dtype=f32, device=dev)
@@ -442,7 +446,8 @@ class JepaEngine:
         _, k0, s0 = c.conv_spec[0]
         ops.conv0_fwd(audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
                       f.ptr32("extract_audio.cnn.0.2.bias"), self.post_ptr[0], self.gn_stats[0], self.gn_stats[1], self.gn_ws,
-                      N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0])
+                      N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
+                      yx=self.gn_yx if torch.is_grad_enabled() else None, x1=self.gn_x1 if torch.is_grad_enabled() else None)
         for l in range(1, len(c.conv_spec)):
             _, k, s = c.conv_spec[l]
             ops.gemm(self.post_ptr[l - 1], self._conv_w[f"wp{l}"], self.pre_ptr[l], C2=self.post_ptr[l], M=N * self.P[l], N=C,
@@ -678,8 +683,9 @@ class JepaEngine:
         ops.conv0_bwd(self.audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
                       f.ptr32("extract_audio.cnn.0.2.bias"), self.gn_stats[0], self.gn_stats[1], self.dpost_ptr[0],
                       f.gptr("extract_audio.cnn.0.0.weight"), f.gptr("extract_audio.cnn.0.2.weight"),
-                      f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws, N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0,
-                      stride=s0, L_out=self.L[0], P=self.P[0])
+                      f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws, yx=self.gn_yx, x1=self.gn_x1, N=N, C_in=c.in_channels,
+                      L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
+                      **(dict(rows=act_rows[0][0], row_off=act_rows[0][2], max_rows=act_rows[0][3]) if sparse else {}))
         if sparse:
             act, n_act, _, _ = act_rows[0]
             ops.zero_rows(self.dpost_ptr[0], act, n_rows=n_act, row_bytes=C * 2)
@@ -701,8 +707,9 @@ class JepaEngine:
         def up(a):
             return torch.from_numpy(np.concatenate([a, pad])).to(self.dev, non_blocking=True)
 
-        out = {l: (up(act), int(act.size), None if ext is None else up(ext), 0 if ext is None else int(ext.size))
-               for l, (act, ext) in lists.items()}
+        out = {l: (up(act), int(act.size), up(ext), int(ext.size)) for l, (act, ext) in lists.items() if l > 0}
+        act0, off0 = lists[0]
+        out[0] = (up(act0), int(act0.size), up(off0), int(np.diff(off0).max()) if off0.size > 1 else 0)   # (rows, n, row_off, max_rows)
         plan._conv_rows = ((self.N, tuple(self.P)), out)
         return out
 

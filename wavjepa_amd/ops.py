@@ -126,19 +126,21 @@ def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: i
 
 # ---------------------------------------------------------------------------------------------------------- conv front-end
 def conv0_fwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, act: Ptr, mean: Ptr, rstd: Ptr, workspace: Ptr, *, N: int,
-              C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int, eps: float = 1e-5,
-              stream: Optional[int] = None) -> None:
+              C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int, eps: float = 1e-5, yx: Ptr = None,
+              x1: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_conv0_gn_gelu_fwd", "wj_conv0_fwd_args", stream, audio=_p(audio), w=_p(w), gamma=_p(gamma), beta=_p(beta),
-         act=_p(act), mean=_p(mean), rstd=_p(rstd), workspace=_p(workspace), N=N, C_in=C_in, L=L, C=C, k=k, stride=stride,
-         L_out=L_out, P=P, eps=eps)
+         act=_p(act), mean=_p(mean), rstd=_p(rstd), workspace=_p(workspace), yx=_p(yx), x1=_p(x1), N=N, C_in=C_in, L=L, C=C,
+         k=k, stride=stride, L_out=L_out, P=P, eps=eps)
 
 
 def conv0_bwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, mean: Ptr, rstd: Ptr, dact: Ptr, dw: Ptr, dgamma: Ptr, dbeta: Ptr,
-              workspace: Ptr, *, N: int, C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int,
-              stream: Optional[int] = None) -> None:
+              workspace: Ptr, *, yx: Ptr, x1: Ptr, N: int, C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int,
+              rows: Ptr = None, row_off: Ptr = None, max_rows: int = 0, stream: Optional[int] = None) -> None:
+    """rows / row_off / max_rows: read the output gradient on the listed rows only (see include/wavjepa_hip.h)."""
     _run("wj_conv0_gn_gelu_bwd", "wj_conv0_bwd_args", stream, audio=_p(audio), w=_p(w), gamma=_p(gamma), beta=_p(beta),
-         mean=_p(mean), rstd=_p(rstd), dact=_p(dact), dw=_p(dw), dgamma=_p(dgamma), dbeta=_p(dbeta), workspace=_p(workspace),
-         N=N, C_in=C_in, L=L, C=C, k=k, stride=stride, L_out=L_out, P=P)
+         mean=_p(mean), rstd=_p(rstd), dact=_p(dact), yx=_p(yx), x1=_p(x1), rows=_p(rows), row_off=_p(row_off), dw=_p(dw),
+         dgamma=_p(dgamma), dbeta=_p(dbeta), workspace=_p(workspace), N=N, C_in=C_in, L=L, C=C, k=k, stride=stride, L_out=L_out,
+         P=P, max_rows=max_rows)
 
 
 def gelu_bwd_bf16(dpost: Ptr, pre: Ptr, dpre: Ptr, n: int, *, rows: Ptr = None, n_rows: int = 0, row_elems: int = 0,
