@@ -1,5 +1,7 @@
+"""Run-to-run reproducibility of one small training step (fp32 atomics in the reductions reorder sums; the noise grows
+down the conv stack).  Yardstick for the sparse-vs-dense and ragged-vs-dense equality tests.  Run on the GPU box."""
 import os, sys, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
 from tests.test_jepa_gpu import build, SMALL
