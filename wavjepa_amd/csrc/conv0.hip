@@ -138,6 +138,136 @@ __global__ __launch_bounds__(NTH) void conv0_stats_kernel(const bf16_t* __restri
     }
 }
 
+// ---- pass 1 on the matrix cores (C % 16 == 0): the conv is a K = taps (padded to 32) MFMA, its bf16-rounded output feeds a
+//      second MFMA with K = time that accumulates YX, so the VALU only rounds and sums.
+//   mfma(P, Q): lane (i, g) gets  sum_k Q[row i][k] P[row 4g+r][k], r < 4;  operand lane (i, g) holds row i, k = 8g .. 8g+7.
+//   conv : P = audio patches (rows = 16 time steps), Q = weights (rows = 16 channels)  -> lane: channel i, times 4g+r
+//   YX   : Q' = that result for two 16-step blocks (row = channel i, logical k = 8g+j <-> time kappa(g,j) = j<4 ? 4g+j : 16+4g+j-4),
+//          P' = audio patches with rows = taps and the same kappa order                  -> lane: channel i, taps 4g+r
+constexpr int TCS = 1024;  // time steps per workgroup (few, long workgroups: 12 atomics per channel per workgroup)
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                               float* __restrict__ sums, float* __restrict__ yx,
+                                                               float* __restrict__ x1, Geo g, int span) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t xa[];   // [C_in][span] samples of this chunk (0 past the clip)
+    constexpr int QT = (TAPS + 15) / 16;
+    const int n = blockIdx.y, t0 = blockIdx.x * TCS;
+    for (int ci = 0; ci < g.C_in; ++ci)
+        for (int i = threadIdx.x; i < span; i += 256) {
+            const long src = (long)t0 * g.stride + i;
+            xa[ci * span + i] = src < g.L ? audio[((long)n * g.C_in + ci) * g.L + src] : f2bf(0.f);
+        }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, gq = lane >> 4;
+    const int tcount = min(TCS, g.L_out - t0);
+    const bf16_t zero = f2bf(0.f);
+    int offc[8];
+    bool okc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = 8 * gq + j, ci = q / g.k;
+        okc[j] = q < TAPS;
+        offc[j] = ci * span + (q - ci * g.k);
+    }
+    int offq[QT];
+    bool okq[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = 16 * qt + i, ci = q / g.k;
+        okq[qt] = q < TAPS;
+        offq[qt] = ci * span + (q - ci * g.k);
+    }
+    const int ntile = g.C / 16;
+    for (int ctg = wave * 8; ctg < ntile; ctg += 32) {            // 8 channel tiles per wave per pass
+        bf16x8 wf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                wf[u][j] = (ctg + u < ntile && okc[j]) ? wsrc[(long)((ctg + u) * 16 + i) * TAPS + 8 * gq + j] : zero;
+        f32x4 yxa[8][QT];
+        float s1[8], s2[8], xs1[QT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s1[u] = s2[u] = 0.f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) yxa[u][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) xs1[qt] = 0.f;
+        for (int tb = 0; tb < tcount; tb += 32) {
+            bf16x8 p0, p1, pq[QT];
+            const bool v0 = tb + i < tcount, v1 = tb + 16 + i < tcount;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p0[j] = (v0 && okc[j]) ? xa[offc[j] + (tb + i) * g.stride] : zero;
+                p1[j] = (v1 && okc[j]) ? xa[offc[j] + (tb + 16 + i) * g.stride] : zero;
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tt = tb + (j < 4 ? 4 * gq + j : 12 + 4 * gq + j);
+                    pq[qt][j] = (okq[qt] && tt < tcount) ? xa[offq[qt] + tt * g.stride] : zero;
+                }
+            if (yx && ctg == 0) {                                  // wave 0's first pass also sums the patches themselves
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs1[qt] += bf2f(pq[qt][j]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, wf[u], z4, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, wf[u], z4, 0, 0, 0);
+                bf16x8 yq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    yq[r] = f2bf(d0[r]);                            // the conv output is a bf16 tensor in the reference flow
+                    yq[4 + r] = f2bf(d1[r]);
+                    const float a = bf2f(yq[r]), b = bf2f(yq[4 + r]);
+                    s1[u] += a + b;
+                    s2[u] = fmaf(a, a, fmaf(b, b, s2[u]));
+                }
+                if (yx) {
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) yxa[u][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pq[qt], yq, yxa[u][qt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ctg + u >= ntile) continue;
+            const int c = (ctg + u) * 16 + i;
+            float a = s1[u], b = s2[u];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (gq == 0) {
+                atomicAdd(sums + ((long)n * g.C + c) * 2 + 0, a);
+                atomicAdd(sums + ((long)n * g.C + c) * 2 + 1, b);
+            }
+            if (yx) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = 16 * qt + 4 * gq + r;
+                        if (q < TAPS) atomicAdd(yx + ((long)n * g.C + c) * TAPS + q, yxa[u][qt][r]);
+                    }
+            }
+        }
+        if (yx && ctg == 0) {                                      // wave 0
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float v = xs1[qt];
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (gq == 0 && okq[qt]) atomicAdd(x1 + (long)n * TAPS + 16 * qt + i, v);
+            }
+        }
+    }
+}
+
 // ---- pass 2 (forward): normalise, GELU, write channels-last bf16; emit mean / rstd ---------------------------
 template <int TAPS>
 __global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
@@ -328,8 +458,15 @@ void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStrea
     const size_t lds = (size_t)a->C_in * span_max * sizeof(float);
     const size_t lds1 = lds + (a->yx ? (size_t)128 * 4 * TAPS * sizeof(float) : 0);
     dim3 grid1((a->L_out + TC - 1) / TC, a->N), grid2((a->P + TC - 1) / TC, a->N), block(NTH);
-    hipLaunchKernelGGL(conv0_stats_kernel<TAPS>, grid1, block, lds1, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
-                       a->workspace, a->yx, a->x1, g, span_max);
+    if (a->C % 16 == 0) {
+        const int span = (TCS - 1) * a->stride + a->k;
+        hipLaunchKernelGGL(conv0_stats_mfma_kernel<TAPS>, dim3((a->L_out + TCS - 1) / TCS, a->N), dim3(256),
+                           (size_t)a->C_in * span * sizeof(bf16_t), s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->workspace,
+                           a->yx, a->x1, g, span);
+    } else {
+        hipLaunchKernelGGL(conv0_stats_kernel<TAPS>, grid1, block, lds1, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
+                           a->workspace, a->yx, a->x1, g, span_max);
+    }
     hipLaunchKernelGGL(conv0_apply_kernel<TAPS>, grid2, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
                        a->gamma, a->beta, (const float*)a->workspace, (bf16_t*)a->act, a->mean, a->rstd, g, span_max, a->eps);
 }
