@@ -54,6 +54,22 @@ def gemm_kernel_name(f) -> str:
     return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
 
 
+def pmc_traffic_for(name: str):
+    """HBM bytes per launch of a GEMM class from the committed PMC summary (profiles/r01_pmc_traffic.json, collected with
+    tools/pmc_traffic.py on this same command): launch-weighted mean over the tile variants of the class, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    m = __import__("re").match(r"gemm_kernel<([NT])([NT]),(\w+)>", name)
+    if not m or not os.path.exists(path):
+        return None
+    epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5}[m.group(3)]
+    prefix = f"gemm3_kernel<{'true' if m.group(1) == 'T' else 'false'}, {'true' if m.group(2) == 'T' else 'false'}, {epi},"
+    with open(path) as fh:
+        kernels = json.load(fh)["kernels"]
+    hits = [v for k, v in kernels.items() if k.startswith(prefix)]
+    n = sum(v["launches"] for v in hits)
+    return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
+
+
 def profile_one_step(runner, source, step_idx: int):
     """Run one extra step with every C-ABI call bracketed by HIP events; returns per-kernel-class totals."""
     from wavjepa_amd import ops
@@ -73,14 +89,18 @@ def profile_one_step(runner, source, step_idx: int):
         ms = e0.elapsed_time(e1)
         if fn == "wj_gemm_bf16":
             name, flops = gemm_kernel_name(f), 2.0 * f["M"] * f["N"] * f["K"]
+            ep = f["epilogue"]
+            outb = 4 if ep in (3, 4) else 2
+            nbytes = 2.0 * f["K"] * (f["M"] + f["N"]) + f["M"] * f["N"] * (outb * (2 if ep in (1, 5) else 1) + (outb if ep in (2, 3) else 0))
             key = f"{name} M={f['M']} N={f['N']} K={f['K']}" + (" gather" if f.get("rowmap") else "")
             sh = shapes.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
             sh["ms"] += ms; sh["flops"] += flops; sh["launches"] += 1
         else:
-            name, flops = fn, 0.0
-        c = classes.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+            name, flops, nbytes = fn, 0.0, 0.0
+        c = classes.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
         c["ms"] += ms
         c["flops"] += flops
+        c["bytes"] += nbytes
         c["launches"] += 1
     profile_one_step.shapes = shapes
     return classes
@@ -205,9 +225,10 @@ def main():
             all_fl = sum(v["flops"] for v in gemms.values())
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, launches_per_step=c["launches"],
+                            frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic_for(name), launches_per_step=c["launches"],
                             avg_launch_ms=round(c["ms"] / c["launches"], 4),
                             gflop_per_launch=round(c["flops"] / c["launches"] / 1e9, 2),
+                            algorithmic_bytes_per_launch=int(c["bytes"] / c["launches"]),   # operands once + outputs (+ addends)
                             all_gemm_achieved=round(all_fl / (all_ms * 1e-3) / 1e12, 1),
                             gemm_share_of_step=round(all_ms / sum(v["ms"] for v in classes.values()), 3))
 
