@@ -200,7 +200,7 @@ def test_gemm_conv_overlapping_rows(ops):
 
 
 # ------------------------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("M,D", [(37, 768), (64, 384), (10, 32), (9, 512), (5, 1024)])
+@pytest.mark.parametrize("M,D", [(37, 768), (64, 384), (67, 384), (10, 32), (9, 512), (5, 1024), (11, 128)])
 def test_layernorm_fwd_bwd(ops, M, D):
     x = rnd(M, D, seed=20)
     r = rnd(M, D, dtype=torch.bfloat16, seed=21)

@@ -9,6 +9,7 @@
 //   forward : S^T -> mask/softmax -> O^T, LSE
 //   backward: phase A (per query tile)  dQ^T = K^T dS^T        with S^T, dP^T = V dO^T recomputed
 //             phase B (per key tile)    dV^T = dO^T P, dK^T = Q^T dS   with S = Q K^T, dP = dO V^T recomputed
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
 
@@ -16,7 +17,8 @@ namespace {
 
 constexpr int MAX_TILES = 14;  // 16-row tiles: T <= 224
 constexpr int NWB64 = 4, NWB32 = 4;   // backward waves per workgroup (more waves measured slower: 339 -> 439 us at hd 64)
-constexpr int NWF = 7;         // forward: 13 query tiles over 7 waves (2,2,2,2,2,2,1) instead of 4 (4,3,3,3)
+constexpr int NWF_LONG = 7;    // forward, T > 128: 13 query tiles over 7 waves (2,2,2,2,2,2,1) instead of 4 (4,3,3,3)
+constexpr int NWF_SHORT = 4;   // forward, T <= 128 (ragged student / predictor): <= 2 tiles per wave, twice the workgroups per CU
 
 template <int HD> struct Img {
     static constexpr int RS = HD * 2 + 32;  // padded row stride in bytes
@@ -26,11 +28,11 @@ template <int HD> struct Img {
 // Copy rows [0,T) of TWO [T][ld] bf16 matrices (HD columns each) into their padded LDS images; rows [T,KP) are zero.
 // All global loads of a thread are issued before its first LDS store (a load->store loop would serialise one HBM/L2
 // round trip per iteration: ~13 of them for a 200 x 64 head).
-template <int HD, int NWAVES>
+template <int HD, int NWAVES, int MT = MAX_TILES>
 __device__ __forceinline__ void fill_images2(char* img0, const bf16_t* __restrict__ src0, long ld0, char* img1,
                                              const bf16_t* __restrict__ src1, long ld1, int T, int KP) {
     constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
-    constexpr int MAXI = (MAX_TILES * 16 * CH + NWAVES * 64 - 1) / (NWAVES * 64);
+    constexpr int MAXI = (MT * 16 * CH + NWAVES * 64 - 1) / (NWAVES * 64);
     uint4 v0[MAXI], v1[MAXI];
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
@@ -99,12 +101,17 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int HD>
-__global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args a) {
+// MT = most 16-row tiles a sequence may have (14: T <= 224; 8: T <= 128, fewer live registers -> more waves per SIMD)
+template <int HD, int NWF, int MT>
+__global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : 6) void attn_fwd_kernel(wj_attn_fwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, D = H * HD;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    // the heads of one sequence read interleaved 2*HD-byte slices of the same rows: keep them on ONE XCD so that the
+    // other half of every 128-B line is an L2 hit (round-robin dispatch would spread them over all eight L2s: PMC showed
+    // the hd = 32 predictor fetching 1.8x (fwd) / 2.6x (bwd) its algorithmic bytes)
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = wg / H, h = wg - b * H;
     int T = a.T;
     long row0 = (long)b * a.T;
     if (a.seq_off) {                     // ragged: this sequence's rows in the packed buffers
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
     bf16x8 qf[KS];                       // this wave's first query tile: in flight while K / V are staged
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, wave * 16, T, ks, lane);
-    fill_images2<HD, NWF>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
+    fill_images2<HD, NWF, MT>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
     for (int k = threadIdx.x; k < KP; k += blockDim.x)
         madd[k] = (k < T && !(km && km[k])) ? 0.f : -INFINITY;
@@ -133,10 +140,10 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
         bf16x8 qn[KS];                   // next tile's fragments: issued now, consumed at the end of this iteration
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NWF) * 16, (qt + NWF < nkt) ? T : 0, ks, lane);
-        f32x4 s[MAX_TILES];
+        f32x4 s[MT];
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < MAX_TILES; ++kt) {
+        for (int kt = 0; kt < MT; ++kt) {
             s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (kt < nkt) {
 #pragma unroll
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
         const float msafe = (mx == -INFINITY) ? 0.f : mx;  // fully masked row: all p = 0 (the reference yields NaN)
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < MAX_TILES; ++kt) {
+        for (int kt = 0; kt < MT; ++kt) {
             if (kt < nkt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < MAX_TILES / 2; ++c) {
+        for (int c = 0; c < MT / 2; ++c) {
             if (c < nch) {
                 const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
                 // probabilities are normalised BEFORE the bf16 rounding (as a materialised softmax would be)
@@ -199,12 +206,13 @@ __global__ __launch_bounds__(NWF * 64, 4) void attn_fwd_kernel(wj_attn_fwd_args 
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int HD, int NWB>
+template <int HD, int NWB, int MT>
 __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj_attn_bwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, D = H * HD;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);   // heads of one sequence on one XCD (see the forward)
+    const int b = wg / H, h = wg - b * H;
     int T = a.T;
     long row0 = (long)b * a.T;
     if (a.seq_off) {
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
     bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HD;
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
-    fill_images2<HD, NWB>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
+    fill_images2<HD, NWB, MT>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
         float l = INFINITY, dl = 0.f, kv = 0.f;
         if (r < T) {
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = zero4;
 #pragma unroll
-        for (int c = 0; c < MAX_TILES / 2; ++c) {
+        for (int c = 0; c < MT / 2; ++c) {
             if (c < nch) {
                 f32x4 ds2[2];
 #pragma unroll
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
             }
     }
     __syncthreads();
-    fill_images2<HD, NWB>(img0, qkv, ld, img1, dO, D, T, KP);
+    fill_images2<HD, NWB, MT>(img0, qkv, ld, img1, dO, D, T, KP);
     __syncthreads();
 
     // ---- phase B: dK, dV for 16 keys per wave iteration (keys on the lane, queries on the accumulator rows)
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = zero4;
 #pragma unroll
-        for (int c = 0; c < MAX_TILES / 2; ++c) {
+        for (int c = 0; c < MT / 2; ++c) {
             if (c < nch) {
                 f32x4 p2[2], ds2[2];
 #pragma unroll
@@ -434,15 +442,18 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     const int KP = ((a->T + 31) / 32) * 32;
     const int lds = 2 * KP * (a->hd * 2 + 32) + KP * 4;
-    dim3 grid(a->B * a->H), block(NWF * 64);
+    dim3 grid(a->B * a->H);
+    hipStream_t st = (hipStream_t)stream;
+    static int once = set_lds(attn_fwd_kernel<64, NWF_LONG, 14>, 2 * 224 * 160 + 224 * 4) | set_lds(attn_fwd_kernel<32, NWF_LONG, 14>, 2 * 224 * 96 + 224 * 4) |
+                      set_lds(attn_fwd_kernel<64, NWF_SHORT, 8>, 2 * 128 * 160 + 128 * 4) | set_lds(attn_fwd_kernel<32, NWF_SHORT, 8>, 2 * 128 * 96 + 128 * 4);
+    (void)once;
+    const bool shortseq = a->T <= 128;
     if (a->hd == 64) {
-        static int once = set_lds(attn_fwd_kernel<64>, 2 * 224 * 160 + 224 * 4);
-        (void)once;
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, lds, (hipStream_t)stream, *a);
+        if (shortseq) hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_SHORT, 8>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_LONG, 14>), grid, dim3(NWF_LONG * 64), lds, st, *a);
     } else {
-        static int once = set_lds(attn_fwd_kernel<32>, 2 * 224 * 96 + 224 * 4);
-        (void)once;
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, lds, (hipStream_t)stream, *a);
+        if (shortseq) hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_SHORT, 8>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_LONG, 14>), grid, dim3(NWF_LONG * 64), lds, st, *a);
     }
     WJ_CHECK_LAUNCH();
     return WJ_OK;
@@ -457,14 +468,17 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     const int KP = ((a->T + 31) / 32) * 32;
     const int lds = 2 * KP * (a->hd * 2 + 32) + 3 * KP * 4 + 3 * a->hd * 4;
     dim3 grid(a->B * a->H);
-    if (a->hd == 64) {
-        static int once = set_lds(attn_bwd_kernel<64, NWB64>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4);
-        (void)once;
-        hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64>), grid, dim3(NWB64 * 64), lds, (hipStream_t)stream, *a);
+    hipStream_t st = (hipStream_t)stream;
+    static int once = set_lds(attn_bwd_kernel<64, NWB64, 14>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4) |
+                      set_lds(attn_bwd_kernel<32, NWB32, 14>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4);
+    (void)once;
+    if (a->T <= 128) {          // ragged student / predictor: at most 8 tiles (6 or 8 waves per workgroup measured 1.5-2x slower)
+        if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 8>), grid, dim3(NWB64 * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 8>), grid, dim3(NWB32 * 64), lds, st, *a);
+    } else if (a->hd == 64) {
+        hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 14>), grid, dim3(NWB64 * 64), lds, st, *a);
     } else {
-        static int once = set_lds(attn_bwd_kernel<32, NWB32>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4);
-        (void)once;
-        hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32>), grid, dim3(NWB32 * 64), lds, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 14>), grid, dim3(NWB32 * 64), lds, st, *a);
     }
     if (a->dbias) {
         wj_colsum_args c;

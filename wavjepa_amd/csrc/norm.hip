@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int MAXV = 4;  // float4 chunks per lane: D <= 1024
+constexpr int MAXV = 4;  // float4 chunks per 64-lane row: D <= 1024
 
 __device__ __forceinline__ long remap_row(int m, int seg, int valid) {
     return seg > 0 ? (long)(m / valid) * seg + (m % valid) : (long)m;
@@ -21,17 +21,39 @@ __device__ __forceinline__ f32x4 load4(const void* base, long row, int D, int co
     return *reinterpret_cast<const f32x4*>((const float*)base + row * D + col);
 }
 
+// LPR lanes own a row (64, or 32 when D is an odd multiple of 128 -- D = 384 would leave a quarter of a 64-lane row idle),
+// V float4 chunks per lane: D <= 4 V LPR.  A wave works on 64 / LPR rows at once.
+template <int V, int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int V, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
+    constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % LPR, sr = lane / LPR;
     const int D = a.D;
     const float invD = 1.0f / (float)D;
-    for (int m = blockIdx.x * 4 + wave; m < a.M; m += gridDim.x * 4) {
+    f32x4 gam[V], bet[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int col = li * 4 + LPR * 4 * j;
+        gam[j] = bet[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < D) {
+            gam[j] = *reinterpret_cast<const f32x4*>(a.gamma + col);
+            bet[j] = *reinterpret_cast<const f32x4*>(a.beta + col);
+        }
+    }
+    for (int m = (blockIdx.x * 4 + wave) * RPW + sr; m < a.M; m += gridDim.x * 4 * RPW) {
         const long xr = remap_row(m, a.in_seg, a.in_valid);
-        f32x4 s[MAXV];
+        f32x4 s[V];
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int col = lane * 4 + 256 * j;
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
             s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (col < D) {
                 s[j] = load4(a.x, xr, D, col, a.x_is_bf16);
@@ -42,11 +64,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
                 sum += s[j][0] + s[j][1] + s[j][2] + s[j][3];
             }
         }
-        const float mean = wave_sum(sum) * invD;
+        const float mean = row_sum<V, LPR>(sum) * invD;
         float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int col = lane * 4 + 256 * j;
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
             if (col < D) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -55,21 +77,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
                 }
             }
         }
-        const float var = wave_sum(sq) * invD;
+        const float var = row_sum<V, LPR>(sq) * invD;
         const float rstd = rsqrtf(var + a.eps);
-        if (lane == 0) {
+        if (li == 0) {
             if (a.mean) a.mean[m] = mean;
             if (a.rstd) a.rstd[m] = rstd;
         }
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int col = lane * 4 + 256 * j;
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
             if (col < D) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + col);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.beta + col);
                 f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (s[j][e] - mean) * rstd * g[e] + b[e];
+                for (int e = 0; e < 4; ++e) y[e] = (s[j][e] - mean) * rstd * gam[j][e] + bet[j][e];
                 if (a.y_f32) *reinterpret_cast<f32x4*>(a.y_f32 + (long)m * D + col) = y;
                 if (a.y_bf16) {
                     bf16x4 o;
@@ -84,28 +104,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
 
 constexpr int BWD_THREADS = 256;
 
-// One wave per row, TWO rows in flight per wave (independent load streams ahead of the shuffle reductions), V float4
-// chunks per lane (D <= 256 V).  Column partials (dgamma, dbeta, dbias) stay in registers across the row loop and are
-// combined through LDS atomics, then one global atomic per column per workgroup.
-template <int V>
+// LPR lanes per row, TWO row slots in flight per wave (independent load streams ahead of the shuffle reductions), V float4
+// chunks per lane (D <= 4 V LPR).  Column partials (dgamma, dbeta, dbias) stay in registers across the row loop and are
+// combined through LDS atomics, then one global atomic per column per workgroup (or a workspace row, folded afterwards).
+template <int V, int LPR>
 __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
-    __shared__ float cacc[3][256 * V];
+    constexpr int RPW = 64 / LPR;
+    constexpr int CW = LPR * 4 * V;                 // columns covered (>= D)
+    __shared__ float cacc[3][CW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % LPR, sr = lane / LPR;
     constexpr int nw = BWD_THREADS / 64;
     const int D = a.D;
     const float invD = 1.0f / (float)D;
-    for (int i = threadIdx.x; i < 3 * 256 * V; i += BWD_THREADS) (&cacc[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 3 * CW; i += BWD_THREADS) (&cacc[0][0])[i] = 0.f;
     __syncthreads();
 
     f32x4 dg[V], db[V], dbi[V], gam[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         dg[j] = db[j] = dbi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int col = lane * 4 + 256 * j;
+        const int col = li * 4 + LPR * 4 * j;
         gam[j] = col < D ? *reinterpret_cast<const f32x4*>(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int stride = gridDim.x * nw;
-    for (int m0 = blockIdx.x * nw + wave; m0 < a.M; m0 += 2 * stride) {
+    const int stride = gridDim.x * nw * RPW;
+    for (int m0 = (blockIdx.x * nw + wave) * RPW + sr; m0 < a.M; m0 += 2 * stride) {
         int mrow[2] = {m0, m0 + stride};
         f32x4 xh[2][V], dy[2][V];
         float mean[2], rstd[2];
@@ -118,7 +141,7 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
             rstd[u] = a.rstd[m];
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const int col = lane * 4 + 256 * j;
+                const int col = li * 4 + LPR * 4 * j;
                 xh[u][j] = dy[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (col < D) {
                     f32x4 sx = load4(a.x, xr, D, col, a.x_is_bf16);
@@ -138,7 +161,7 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const int col = lane * 4 + 256 * j;
+                const int col = li * 4 + LPR * 4 * j;
                 if (col < D) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
                 }
             }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {      // four reductions interleaved
+        for (int o = LPR / 2; o > 0; o >>= 1) {      // four reductions interleaved
             c1[0] += __shfl_xor(c1[0], o, 64); c2[0] += __shfl_xor(c2[0], o, 64);
             c1[1] += __shfl_xor(c1[1], o, 64); c2[1] += __shfl_xor(c2[1], o, 64);
         }
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
             const long orow = remap_row(m, a.out_seg, a.out_valid);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const int col = lane * 4 + 256 * j;
+                const int col = li * 4 + LPR * 4 * j;
                 if (col < D) {
                     f32x4 ds;
                     bf16x4 dsb;
@@ -180,15 +203,27 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
             }
         }
     }
+    if constexpr (RPW == 2) {                       // fold the two sub-rows of the wave before touching LDS
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int col = lane * 4 + 256 * j;
-        if (col < D) {
+        for (int j = 0; j < V; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                atomicAdd(&cacc[0][col + e], dg[j][e]);
-                atomicAdd(&cacc[1][col + e], db[j][e]);
-                if (a.dbias) atomicAdd(&cacc[2][col + e], dbi[j][e]);
+                dg[j][e] += __shfl_xor(dg[j][e], 32, 64);
+                db[j][e] += __shfl_xor(db[j][e], 32, 64);
+                dbi[j][e] += __shfl_xor(dbi[j][e], 32, 64);
+            }
+    }
+    if (sr == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
+            if (col < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(&cacc[0][col + e], dg[j][e]);
+                    atomicAdd(&cacc[1][col + e], db[j][e]);
+                    if (a.dbias) atomicAdd(&cacc[2][col + e], dbi[j][e]);
+                }
             }
         }
     }
@@ -277,9 +312,23 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
     if (!a || !a->x || !a->gamma || !a->beta) return WJ_ERR_ARG;
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if (a->in_seg > 0 && a->in_valid <= 0) return WJ_ERR_ARG;
-    int grid = (a->M + 3) / 4;
+    const bool half = (a->D % 128 == 0) && (a->D % 256 != 0) && a->D <= 384;   // 128 / 384: 32 lanes per row
+    const int rpw = half ? 2 : 1;
+    int grid = (a->M + 4 * rpw - 1) / (4 * rpw);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    dim3 g(grid), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (half) {
+        if (a->D == 128) hipLaunchKernelGGL((ln_fwd_kernel<1, 32>), g, b, 0, s, *a);
+        else hipLaunchKernelGGL((ln_fwd_kernel<3, 32>), g, b, 0, s, *a);
+    } else {
+        switch ((a->D + 255) / 256) {
+            case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, 64>), g, b, 0, s, *a); break;
+            case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, 64>), g, b, 0, s, *a); break;
+            case 3: hipLaunchKernelGGL((ln_fwd_kernel<3, 64>), g, b, 0, s, *a); break;
+            default: hipLaunchKernelGGL((ln_fwd_kernel<4, 64>), g, b, 0, s, *a); break;
+        }
+    }
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }
@@ -289,14 +338,24 @@ extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if ((a->in_seg > 0 && a->in_valid <= 0) || (a->out_seg > 0 && a->out_valid <= 0)) return WJ_ERR_ARG;
     const int nw = BWD_THREADS / 64;
-    int grid = (a->M + 2 * nw - 1) / (2 * nw);
+    const bool half = (a->D % 128 == 0) && (a->D % 256 != 0) && a->D <= 384;
+    const int rpw = half ? 2 : 1;
+    // >= 8 rows per wave (4 passes of its two row slots): with fewer the per-workgroup epilogue (LDS fold, partials store)
+    // dominates -- the ragged student's 10 k rows ran at 1.4 TB/s with one pass per wave
+    int grid = (a->M + 8 * nw * rpw - 1) / (8 * nw * rpw);
     if (grid > 1536) grid = 1536;
-    const int V = (a->D + 255) / 256;
-    switch (V) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
-        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(BWD_THREADS), 0, (hipStream_t)stream, *a); break;
+    dim3 g(grid), b(BWD_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (half) {
+        if (a->D == 128) hipLaunchKernelGGL((ln_bwd_kernel<1, 32>), g, b, 0, s, *a);
+        else hipLaunchKernelGGL((ln_bwd_kernel<3, 32>), g, b, 0, s, *a);
+    } else {
+        switch ((a->D + 255) / 256) {
+            case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 64>), g, b, 0, s, *a); break;
+            case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 64>), g, b, 0, s, *a); break;
+            case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 64>), g, b, 0, s, *a); break;
+            default: hipLaunchKernelGGL((ln_bwd_kernel<4, 64>), g, b, 0, s, *a); break;
+        }
     }
     if (a->workspace && (a->dgamma || a->dbeta || a->dbias))
         launch_colsum_f32(a->workspace, 3L * a->D, grid, 3 * a->D, a->dgamma, a->dbeta, a->dbias, a->D, (hipStream_t)stream);
