@@ -54,6 +54,7 @@ SHAPES = [
     ("rag dec dW1   TT", 1, 1, ops.EPI_ATOMIC_F32, 1536, 384, 86317),
     ("rag dec dW2   TT", 1, 1, ops.EPI_ATOMIC_F32, 384, 1536, 86317),
     ("rag dec dWo   TT", 1, 1, ops.EPI_ATOMIC_F32, 384, 384, 86317),
+    ("square 8192   NN", 0, 0, ops.EPI_BF16, 8192, 8192, 8192),
     ("conv1 fwd     NN", 0, 0, ops.EPI_CONV_GELU, 256 * 3216, 512, 1536),
     ("conv1 wgrad   TT", 1, 1, ops.EPI_ATOMIC_F32, 512, 1536, 256 * 3216),
 ]

@@ -114,6 +114,50 @@ __device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restr
     }
 }
 
+// Loop-invariant form of stage_tile for K tiles that lie entirely inside [kbeg, kend): the per-lane source pointers are
+// computed once and advanced by a constant per tile.  Why it matters: while the partner wave of a SIMD runs its MFMA cluster,
+// the loading wave gets ONE vector-issue slot per 16-cycle MFMA, so every VALU instruction of address arithmetic in the LOAD
+// segment costs ~16 cycles (s_memtime stamps: 730 cycles of LOAD against 557 of COMPUTE with the arithmetic inline).
+template <bool TRANS, int ROWS>
+struct TilePtrs {
+    static constexpr int PER_WAVE = ROWS * BK * 2 / 1024 / 8;
+    const char* p[PER_WAVE];
+    unsigned step[PER_WAVE];   // bytes per K tile; 0 for lanes parked on the zero page (col form, column out of range)
+
+    __device__ __forceinline__ void init(const bf16_t* __restrict__ base, long ld, int r0, int R, int kbeg, int wave, int lane,
+                                         const bf16_t* zero) {
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) {
+            const int j = wave * PER_WAVE + u;
+            if constexpr (!TRANS) {
+                const int row = j * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ row_swz(row);
+                int grow = r0 + row;
+                grow = grow < R ? grow : R - 1;
+                p[u] = reinterpret_cast<const char*>(base + (long)grow * ld + kbeg + c * 8);
+                step[u] = BK * 2;
+            } else {
+                constexpr int CPR = ROWS / 8, RPI = 64 / CPR;
+                const int krow = j * RPI + lane / CPR;
+                const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+                const int c = (lane % CPR) ^ (f << 1);
+                const int row = r0 + c * 8;
+                const bool ok = row < R;
+                p[u] = reinterpret_cast<const char*>(sel_ptr(ok, base + (long)(kbeg + krow) * ld + row, zero));
+                step[u] = ok ? (unsigned)(BK * ld * 2) : 0u;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue_and_advance(char* lds_tile, int wave) {
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) {
+            const int j = wave * PER_WAVE + u;
+            __builtin_amdgcn_global_load_lds((gl_void*)p[u], (lds_void*)(lds_tile + j * 1024), 16, 0, 0);
+            p[u] += step[u];
+        }
+    }
+};
+
 // ---- LDS -> 4 MFMA fragments (tile rows rbase0 + 16x + i, k = 8g + 0..7; i = lane&15, g = lane>>4) ---------------
 template <bool TRANS, int ROWS>
 __device__ __forceinline__ void load_frags4(bf16x8* f, const char* tile, int rbase0, int lane) {
@@ -227,6 +271,23 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
         kidx[0] = v[0]; kidx[1] = v[1]; kidx[2] = v[2]; kidx[3] = v[3];
     };
 
+    // dense forms: loop-invariant source pointers (tiles inside [kbeg, kend)); the K tail tile, if any, takes stage_tile
+    TilePtrs<AT, BM> pa;
+    TilePtrs<BT, BN> pb;
+    if constexpr (GATHER == 0) {
+        pa.init(A, lda, m0, M, kbeg, wave, lane, zero);
+        pb.init(B, ldb, n0, N, kbeg, wave, lane, zero);
+    }
+    auto stage_dense = [&](char* st, int k0) {
+        if (k0 + BK <= kend) {
+            pa.issue_and_advance(st, wave);
+            pb.issue_and_advance(st + A_BYTES, wave);
+        } else {
+            stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
+            stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+        }
+    };
+
     if (nkt > 0) {
 #pragma unroll
         for (int p = 0; p < S - 1; ++p) {
@@ -235,9 +296,11 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                     load_kidx(kbeg + p * BK);
                     stage_tile<AT, BM, true>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero, kidx);
                     stage_tile<BT, BN, true>(smem + p * STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + p * BK, kend, wave, lane, zero, kidx);
-                } else {
-                    stage_tile<AT, BM, GATHER == 1>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero, arow);
+                } else if constexpr (GATHER == 1) {
+                    stage_tile<AT, BM, true>(smem + p * STAGE_BYTES, A, lda, m0, M, kbeg + p * BK, kend, wave, lane, zero, arow);
                     stage_tile<BT, BN>(smem + p * STAGE_BYTES + A_BYTES, B, ldb, n0, N, kbeg + p * BK, kend, wave, lane, zero);
+                } else {
+                    stage_dense(smem + p * STAGE_BYTES, kbeg + p * BK);
                 }
             }
         }
@@ -260,9 +323,11 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                         stage_tile<AT, BM, true>(st, A, lda, m0, M, k0, kend, wave, lane, zero, kidx);
                         stage_tile<BT, BN, true>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero, kidx);
                         load_kidx(k0 + BK);                       // next iteration's tile: the scalar load has a whole tile to land
-                    } else {
-                        stage_tile<AT, BM, GATHER == 1>(st, A, lda, m0, M, k0, kend, wave, lane, zero, arow);
+                    } else if constexpr (GATHER == 1) {
+                        stage_tile<AT, BM, true>(st, A, lda, m0, M, k0, kend, wave, lane, zero, arow);
                         stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+                    } else {
+                        stage_dense(st, k0);
                     }
                 }
                 const char* sa = smem + cur * STAGE_BYTES;
@@ -300,9 +365,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
                 if (kt + S - 1 < nkt) {
                     const int nxt = cur == 0 ? S - 1 : cur - 1;   // stage of tile kt-1: both groups read it >= 1 barrier ago
                     char* st = smem + nxt * STAGE_BYTES;
-                    const int k0 = kbeg + (kt + S - 1) * BK;
-                    stage_tile<AT, BM>(st, A, lda, m0, M, k0, kend, wave, lane, zero);
-                    stage_tile<BT, BN>(st + A_BYTES, B, ldb, n0, N, k0, kend, wave, lane, zero);
+                    stage_dense(st, kbeg + (kt + S - 1) * BK);
                 }
 #endif
                 const char* sa = smem + cur * STAGE_BYTES;
