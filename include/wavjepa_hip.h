@@ -76,6 +76,8 @@ int wj_gemm_bf16(const wj_gemm_args*, void* stream);
  *   s = x (+ r);  y = (s - mean) * rstd * gamma + beta
  *   x: f32, or bf16 when x_is_bf16;  r: bf16 or NULL;  outputs y_f32 / y_bf16 / mean / rstd are each optional.
  *   Input row m is read at row (m / in_valid) * in_seg + (m % in_valid) when in_seg > 0 (padded conv token buffer).
+ *   group_stats (optional, f32 [ceil(M / group_rows)][2], zeroed by the caller): += (sum y, sum y^2) of the f32 output over
+ *   every group of group_rows consecutive rows -- the per-clip statistic wj_instnorm_mean needs (teacher, jepa.py:244-252).
  * -----------------------------------------------------------------------------------------------------------*/
 typedef struct {
     const void* x;
@@ -86,9 +88,11 @@ typedef struct {
     void* y_bf16;
     float* mean;
     float* rstd;
+    float* group_stats;
     int32_t M, D;
     int32_t x_is_bf16;
     int32_t in_seg, in_valid;
+    int32_t group_rows;
     float eps;
 } wj_ln_fwd_args;
 int wj_layernorm_fwd(const wj_ln_fwd_args*, void* stream);
@@ -330,6 +334,19 @@ typedef struct {
     float scale, eps;
 } wj_instnorm_args;
 int wj_instnorm_accumulate(const wj_instnorm_args*, void* stream);
+
+/* The same targets in ONE pass over the K kept layer outputs (K <= 8), given their per-sample (sum, sum of squares):
+ *   targets[b] = (1/K) sum_l (x_l[b] - mean_lb) * rsqrt(var_lb + eps),  mean = S1/TD, var = S2/TD - mean^2 (biased).
+ * stats: f32 [K][B][2] as accumulated by wj_layernorm_fwd.group_stats.  Replaces K read-twice + read-modify-write passes. */
+typedef struct {
+    const float* x0; const float* x1; const float* x2; const float* x3;
+    const float* x4; const float* x5; const float* x6; const float* x7;
+    const float* stats;
+    float* targets;
+    int32_t B, TD, K;
+    float eps;
+} wj_instnorm_mean_args;
+int wj_instnorm_mean(const wj_instnorm_mean_args*, void* stream);
 
 /* Masked MSE (jepa.py:335-362).  preds bf16 [B*G][T][D], targets f32 [B][T][D], tgt u8 [B][G][T].
  *   loss[0] = sum_{tgt} mean_d (p - y)^2 / (count + 1e-8);  loss[1] = count.

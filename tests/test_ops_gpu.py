@@ -557,6 +557,22 @@ def test_instnorm_and_mse(ops):
         ops.instnorm_accumulate(x, tg, B=B, TD=T * D, accumulate=i > 0, scale=1.0 / K)
     ref = torch.stack([F.instance_norm(x.transpose(1, 2)[None])[0].transpose(1, 2) for x in layers]).mean(0)
     assert relerr(tg, ref) < 1e-5
+    # one-pass form: the layer outputs come out of LayerNorm together with their per-sample (sum, sum of squares)
+    g = 1 + 0.1 * rnd(D, seed=77)
+    b = 0.1 * rnd(D, seed=78)
+    stats = torch.zeros(K, B, 2, device=dev())
+    outs = []
+    for i, x in enumerate(layers):
+        y = torch.empty(B * T, D, device=dev())
+        ops.layernorm_fwd(x.reshape(B * T, D), g, b, M=B * T, D=D, eps=1e-6, y_f32=y, group_stats=stats[i], group_rows=T)
+        outs.append(y)
+        yr = F.layer_norm(x, (D,), g, b, 1e-6)
+        assert relerr(stats[i, :, 0], yr.sum((1, 2))) < 1e-4 or maxerr(stats[i, :, 0], yr.sum((1, 2))) < 0.5
+        assert relerr(stats[i, :, 1], (yr * yr).sum((1, 2))) < 1e-5
+    tg2 = torch.empty(B, T, D, device=dev())
+    ops.instnorm_mean(outs, stats, tg2, B=B, TD=T * D)
+    ref2 = torch.stack([F.instance_norm(F.layer_norm(x, (D,), g, b, 1e-6).transpose(1, 2)[None])[0].transpose(1, 2) for x in layers]).mean(0)
+    assert relerr(tg2, ref2) < 2e-5
 
     preds = rnd(B * G, T, D, dtype=torch.bfloat16, seed=75)
     g = torch.Generator().manual_seed(76)

@@ -279,6 +279,37 @@ __global__ __launch_bounds__(1024) void instnorm_kernel(wj_instnorm_args a) {
     }
 }
 
+// one pass over the K kept layer outputs: block = 1024 x float4 of one sample
+__global__ __launch_bounds__(256) void instnorm_mean_kernel(wj_instnorm_mean_args a) {
+    const int b = blockIdx.y;
+    const float* xs[8] = {a.x0, a.x1, a.x2, a.x3, a.x4, a.x5, a.x6, a.x7};
+    const float invn = 1.0f / (float)a.TD, invk = 1.0f / (float)a.K;
+    float mu[8], sc[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        mu[l] = sc[l] = 0.f;
+        if (l < a.K) {
+            const float s1 = a.stats[((long)l * a.B + b) * 2], s2 = a.stats[((long)l * a.B + b) * 2 + 1];
+            mu[l] = s1 * invn;
+            sc[l] = rsqrtf(fmaxf(s2 * invn - mu[l] * mu[l], 0.f) + a.eps) * invk;
+        }
+    }
+    const long base = (long)b * a.TD;
+    const int n4 = a.TD / 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            if (l < a.K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xs[l] + base + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e] - mu[l], sc[l], o[e]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(a.targets + base + i * 4) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- masked MSE
 __global__ __launch_bounds__(1024) void mse_count_kernel(const uint8_t* __restrict__ tgt, float* __restrict__ ws, long n) {
     __shared__ float red[16];
@@ -465,7 +496,7 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_attn_bwd_args) WJ_SZ(wj_conv0_fwd_args) WJ_SZ(wj_conv0_bwd_args) WJ_SZ(wj_gelu_bwd_args) WJ_SZ(wj_conv_w_args)
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
-    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args)
+    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args)
 #undef WJ_SZ
     return -1;
 }
@@ -560,6 +591,18 @@ extern "C" int wj_unmask_rows_f32(const wj_unmask_rows_args* a, void* stream) {
 extern "C" int wj_instnorm_accumulate(const wj_instnorm_args* a, void* stream) {
     if (!a || !a->x || !a->targets || a->B <= 0 || a->TD <= 0 || (a->TD & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(instnorm_kernel, dim3(a->B), dim3(1024), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_instnorm_mean(const wj_instnorm_mean_args* a, void* stream) {
+    if (!a || !a->stats || !a->targets || a->B <= 0 || a->TD <= 0 || (a->TD & 3) || a->K < 1 || a->K > 8) return WJ_ERR_ARG;
+    const float* xs[8] = {a->x0, a->x1, a->x2, a->x3, a->x4, a->x5, a->x6, a->x7};
+    for (int l = 0; l < a->K; ++l)
+        if (!xs[l]) return WJ_ERR_ARG;
+    int gx = (a->TD / 4 + 255) / 256;
+    if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(instnorm_mean_kernel, dim3(gx, a->B), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

@@ -336,6 +336,10 @@ class JepaEngine:
         self.dec_fr = torch.empty(Mp, dtype=f32, device=dev)
         self.preds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
         self.targets = torch.empty(M, c.d_enc, dtype=f32, device=dev)
+        # teacher: outputs of the last top_k layers (fp32) and their per-clip (sum, sum of squares)
+        nkeep = c.top_k if 1 < c.top_k <= 8 else 0
+        self.tea_keep = [torch.empty(M, c.d_enc, dtype=f32, device=dev) for _ in range(nkeep)]
+        self.tea_stats = torch.zeros(max(nkeep, 1), N, 2, dtype=f32, device=dev)
         self.loss = torch.zeros(2, dtype=f32, device=dev)
         self.mse_ws = torch.empty(2 + Mp, dtype=f32, device=dev)
         # backward scratch, one set per stack width
@@ -360,7 +364,8 @@ class JepaEngine:
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
-                   mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None, save: bool = True) -> None:
+                   mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None, save: bool = True,
+                   x2_out: Optional[torch.Tensor] = None, x2_stats: Optional[torch.Tensor] = None) -> None:
         """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1)))).
         `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask.
         save=False (teacher / inference): nothing is kept for a backward (no gelu' output, no softmax statistics)."""
@@ -377,7 +382,10 @@ class JepaEngine:
         else:
             ops.gemm(a.x1b, w.w1, a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU)
         ops.gemm(a.g, w.w2, a.f, M=M, N=D, K=4 * D, lda=4 * D, ldb=4 * D, ldc=D, bias=w.b2)
-        ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2, y_bf16=a.x2b, mean=a.m2, rstd=a.r2)
+        # x2_out / x2_stats (teacher): the layer output goes to its own buffer and its per-clip (sum, sum of squares) is
+        # accumulated on the way, so that the targets are ONE pass over the kept layers (wj_instnorm_mean)
+        ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2 if x2_out is None else x2_out, y_bf16=a.x2b,
+                          mean=a.m2, rstd=a.r2, group_stats=x2_stats, group_rows=self.T if x2_stats is not None else 0)
 
     def _wgrad(self, dY, X, gW, n_out: int, k_in: int, m_tok: int) -> None:
         """gW[n_out, k_in] += dY[m_tok, n_out]^T @ X[m_tok, k_in]"""
@@ -545,17 +553,26 @@ class JepaEngine:
         c, N, M, De = self.cfg, self.N, self.M, self.cfg.d_enc
         a = self.scratch
         x, xb = self.lf, self.lf_b
+        fused = 1 < c.top_k <= 8
+        if fused:
+            self.tea_stats.zero_()
         kept = 0
         for i, w in enumerate(self.tea_layers):
-            self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False)
-            # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
-            # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
-            x, xb = a.x2, a.x2b
-            if c.l_enc - i <= c.top_k:
-                if c.top_k > 1:
+            keep = c.l_enc - i <= c.top_k
+            if keep and fused:
+                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, x2_out=self.tea_keep[kept], x2_stats=self.tea_stats[kept])
+                x, xb = self.tea_keep[kept], a.x2b
+            else:
+                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False)
+                # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
+                # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
+                x, xb = a.x2, a.x2b
+                if keep and c.top_k > 1:
                     ops.instnorm_accumulate(x, self.targets, B=N, TD=self.T * De, accumulate=kept > 0, scale=1.0 / c.top_k)
-                kept += 1
-        if c.top_k <= 1:
+            kept += int(keep)
+        if fused:
+            ops.instnorm_mean(self.tea_keep[:kept], self.tea_stats, self.targets, B=N, TD=self.T * De)
+        elif c.top_k <= 1:
             self.targets.copy_(x)
 
     # ------------------------------------------------------------------------------------------------ backward

@@ -85,10 +85,10 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 # ---------------------------------------------------------------------------------------------------------- norms
 def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, r: Ptr = None, y_f32: Ptr = None,
                   y_bf16: Ptr = None, mean: Ptr = None, rstd: Ptr = None, x_is_bf16: bool = False, in_seg: int = 0,
-                  in_valid: int = 0, stream: Optional[int] = None) -> None:
+                  in_valid: int = 0, group_stats: Ptr = None, group_rows: int = 0, stream: Optional[int] = None) -> None:
     _run("wj_layernorm_fwd", "wj_ln_fwd_args", stream, x=_p(x), r=_p(r), gamma=_p(gamma), beta=_p(beta), y_f32=_p(y_f32),
-         y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg,
-         in_valid=in_valid, eps=eps)
+         y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), group_stats=_p(group_stats), M=M, D=D, x_is_bf16=int(x_is_bf16),
+         in_seg=in_seg, in_valid=in_valid, group_rows=group_rows, eps=eps)
 
 
 def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
@@ -198,6 +198,12 @@ def instnorm_accumulate(x: Ptr, targets: Ptr, *, B: int, TD: int, accumulate: bo
                         stream: Optional[int] = None) -> None:
     _run("wj_instnorm_accumulate", "wj_instnorm_args", stream, x=_p(x), targets=_p(targets), B=B, TD=TD,
          accumulate=int(accumulate), scale=scale, eps=eps)
+
+
+def instnorm_mean(xs, stats: Ptr, targets: Ptr, *, B: int, TD: int, eps: float = 1e-5, stream: Optional[int] = None) -> None:
+    """targets = mean over the K = len(xs) <= 8 tensors of their per-sample instance norm, from precomputed (sum, sumsq)."""
+    kw = {f"x{i}": _p(x) for i, x in enumerate(xs)}
+    _run("wj_instnorm_mean", "wj_instnorm_mean_args", stream, stats=_p(stats), targets=_p(targets), B=B, TD=TD, K=len(xs), eps=eps, **kw)
 
 
 def masked_mse(preds: Ptr, targets: Ptr, tgt: Ptr, loss: Ptr, workspace: Ptr, *, B: int, G: int, T: int, D: int,
