@@ -93,6 +93,11 @@ def load():
         raise WavJepaHipError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m wavjepa_amd.build` "
             "(or __graft_entry__.build()). wavjepa_amd has no CPU/PyTorch fallback by design.")
+    # PyTorch-ROCm ships its own libamdhip64; the library must bind to THAT runtime (the one that owns the tensors and streams
+    # it is handed), so torch is loaded first and the dynamic linker resolves our libamdhip64 dependency to the copy already
+    # in the process.  Loaded the other way round there are two HIP runtimes and the first launch fails with "no ROCm-capable
+    # device is detected".
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -436,6 +436,7 @@ int set_lds(K kern, int bytes) {
 }  // namespace
 
 extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->qkv || !a->out) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
@@ -460,6 +461,7 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
 }
 
 extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->dqkv) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->seq_off && a->key_mask) return WJ_ERR_ARG;

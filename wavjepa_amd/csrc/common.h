@@ -2,6 +2,8 @@
 // Wavefront = 64 lanes everywhere in this tree; nothing here is portable to 32-wide hardware.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 typedef __bf16 bf16_t;
@@ -16,10 +18,17 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define WJ_ERR_LAUNCH (-2)
 #define WJ_ERR_UNSUPPORTED (-3)
 
-#define WJ_CHECK_LAUNCH()                                   \
-    do {                                                    \
-        hipError_t e__ = hipGetLastError();                 \
-        if (e__ != hipSuccess) return WJ_ERR_LAUNCH;        \
+// hipGetLastError() reports the last error of ANY HIP call of this thread -- including benign ones of the host framework (an
+// event query returning hipErrorNotReady) -- so every entry point first discards what it did not cause.
+#define WJ_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
+#define WJ_CHECK_LAUNCH()                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = hipGetLastError();                                                            \
+        if (e__ != hipSuccess) {                                                                       \
+            if (getenv("WJ_DEBUG")) fprintf(stderr, "[wavjepa_hip] %s: %s\n", __func__, hipGetErrorString(e__)); \
+            return WJ_ERR_LAUNCH;                                                                      \
+        }                                                                                              \
     } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }

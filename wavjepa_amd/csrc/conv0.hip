@@ -488,6 +488,7 @@ void launch_bwd(const wj_conv0_bwd_args* a, const Geo& g, hipStream_t s) {
 }  // namespace
 
 extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->audio || !a->w || !a->gamma || !a->beta || !a->act || !a->mean || !a->rstd || !a->workspace) return WJ_ERR_ARG;
     if (a->N <= 0 || a->C <= 0 || (a->C & 3) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
     if ((a->L_out - 1) * a->stride + a->k > a->L) return WJ_ERR_ARG;
@@ -511,6 +512,7 @@ extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
 }
 
 extern "C" int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->audio || !a->w || !a->gamma || !a->beta || !a->mean || !a->rstd || !a->dact || !a->dw || !a->dgamma ||
         !a->dbeta || !a->workspace || !a->yx || !a->x1)
         return WJ_ERR_ARG;

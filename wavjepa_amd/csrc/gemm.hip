@@ -661,6 +661,7 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
 }  // namespace
 
 extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->A || !a->B || !a->C) return WJ_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return WJ_ERR_ARG;
     if ((a->N & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 7)) return WJ_ERR_ARG;

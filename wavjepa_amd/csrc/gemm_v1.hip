@@ -282,6 +282,7 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
 
 // Generation-1 kernel (128x128 tile, register staging), kept for A/B comparison: set WJ_GEMM_V1=1.
 extern "C" int wj_gemm_bf16_v1(const wj_gemm_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (a && a->colsum) return WJ_ERR_UNSUPPORTED;  // the generation-1 kernel has no fused column sums
     if (!a || !a->A || !a->B || !a->C) return WJ_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return WJ_ERR_ARG;

@@ -502,6 +502,7 @@ extern "C" int wj_struct_size(const char* name) {
 }
 
 extern "C" int wj_gelu_bwd_bf16(const wj_gelu_bwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (a && a->rows) {
         if (!a->dpost || !a->pre || !a->dpre || a->n_rows < 0 || a->row_elems <= 0 || (a->row_elems & 7)) return WJ_ERR_ARG;
         if (a->n_rows == 0) return WJ_OK;
@@ -519,6 +520,7 @@ extern "C" int wj_gelu_bwd_bf16(const wj_gelu_bwd_args* a, void* stream) {
 }
 
 extern "C" int wj_zero_rows(const wj_zero_rows_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->buf || !a->rows || a->n_rows < 0 || a->row_bytes <= 0 || (a->row_bytes & 15)) return WJ_ERR_ARG;
     if (a->n_rows == 0) return WJ_OK;
     hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long)a->n_rows * (a->row_bytes / 16), 256)), dim3(256), 0, STREAM,
@@ -528,6 +530,7 @@ extern "C" int wj_zero_rows(const wj_zero_rows_args* a, void* stream) {
 }
 
 extern "C" int wj_conv_weight_layout(const wj_conv_w_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->src || !a->dst || a->C_out <= 0 || a->C_in <= 0 || a->k <= 0 || a->mode < 0 || a->mode > 2) return WJ_ERR_ARG;
     if (a->mode == 1 && (a->U <= 0 || a->rho < 0 || a->rho + a->stride * (a->U - 1) >= a->k)) return WJ_ERR_ARG;
     const long n = a->mode == 1 ? (long)a->U * a->C_out * a->C_in : (long)a->C_out * a->C_in * a->k;
@@ -537,6 +540,7 @@ extern "C" int wj_conv_weight_layout(const wj_conv_w_args* a, void* stream) {
 }
 
 extern "C" int wj_add_pos(const wj_add_pos_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->x || !a->pos || a->M <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for((long)a->M * a->D / 4, 256)), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
@@ -544,6 +548,7 @@ extern "C" int wj_add_pos(const wj_add_pos_args* a, void* stream) {
 }
 
 extern "C" int wj_mask_gather_rows(const wj_gather_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->x || !a->idx || !a->out || a->n_rows < 0 || a->D <= 0) return WJ_ERR_ARG;
     if (a->elem_bytes != 2 && a->elem_bytes != 4) return WJ_ERR_ARG;
     const int row_bytes = a->D * a->elem_bytes;
@@ -556,6 +561,7 @@ extern "C" int wj_mask_gather_rows(const wj_gather_args* a, void* stream) {
 }
 
 extern "C" int wj_mask_scatter_fill_pos(const wj_scatter_fill_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->ctx_feats || !a->inv || !a->mask_token || !a->pos || a->B <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3) ||
         a->G <= 0)
         return WJ_ERR_ARG;
@@ -572,6 +578,7 @@ extern "C" int wj_mask_scatter_fill_pos(const wj_scatter_fill_args* a, void* str
 }
 
 extern "C" int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->d_in || !a->inv || !a->d_ctx_feats || a->B <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3) || a->D > 1024 ||
         a->G <= 0)
         return WJ_ERR_ARG;
@@ -582,6 +589,7 @@ extern "C" int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args* a, v
 }
 
 extern "C" int wj_unmask_rows_f32(const wj_unmask_rows_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->src || !a->dst || a->M <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(unmask_rows_kernel, dim3(grid_for((long)a->M * a->D / 4, 256)), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
@@ -589,6 +597,7 @@ extern "C" int wj_unmask_rows_f32(const wj_unmask_rows_args* a, void* stream) {
 }
 
 extern "C" int wj_instnorm_accumulate(const wj_instnorm_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->x || !a->targets || a->B <= 0 || a->TD <= 0 || (a->TD & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(instnorm_kernel, dim3(a->B), dim3(1024), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
@@ -596,6 +605,7 @@ extern "C" int wj_instnorm_accumulate(const wj_instnorm_args* a, void* stream) {
 }
 
 extern "C" int wj_instnorm_mean(const wj_instnorm_mean_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->stats || !a->targets || a->B <= 0 || a->TD <= 0 || (a->TD & 3) || a->K < 1 || a->K > 8) return WJ_ERR_ARG;
     const float* xs[8] = {a->x0, a->x1, a->x2, a->x3, a->x4, a->x5, a->x6, a->x7};
     for (int l = 0; l < a->K; ++l)
@@ -608,6 +618,7 @@ extern "C" int wj_instnorm_mean(const wj_instnorm_mean_args* a, void* stream) {
 }
 
 extern "C" int wj_masked_mse(const wj_mse_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->preds || !a->targets || !a->tgt || !a->loss || !a->workspace) return WJ_ERR_ARG;
     if (a->B <= 0 || a->G <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3)) return WJ_ERR_ARG;
     const long Rd = (long)a->B * a->G * a->T;          // dense positions (the target count runs over all of them)
@@ -621,6 +632,7 @@ extern "C" int wj_masked_mse(const wj_mse_args* a, void* stream) {
 }
 
 extern "C" int wj_ema_update(const wj_ema_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->student || !a->teacher || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(ema_kernel, dim3(grid_for(a->n / 4, 256)), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
@@ -628,6 +640,7 @@ extern "C" int wj_ema_update(const wj_ema_args* a, void* stream) {
 }
 
 extern "C" int wj_grad_sumsq(const wj_sumsq_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->g || !a->out || !a->workspace || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
     const int grid = grid_for(a->n / 4, 256, 1024);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, STREAM, a->g, a->workspace, (long)a->n);
@@ -637,6 +650,7 @@ extern "C" int wj_grad_sumsq(const wj_sumsq_args* a, void* stream) {
 }
 
 extern "C" int wj_adamw_step(const wj_adamw_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n / 4, 256)), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
@@ -644,6 +658,7 @@ extern "C" int wj_adamw_step(const wj_adamw_args* a, void* stream) {
 }
 
 extern "C" int wj_cast_f32_to_bf16(const wj_cast_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->src || !a->dst || a->n <= 0) return WJ_ERR_ARG;
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(a->n / 4 + 1, 256)), dim3(256), 0, STREAM, a->src, (bf16_t*)a->dst, (long)a->n);
     WJ_CHECK_LAUNCH();
@@ -651,6 +666,7 @@ extern "C" int wj_cast_f32_to_bf16(const wj_cast_args* a, void* stream) {
 }
 
 extern "C" int wj_crop_normalize_bf16(const wj_crop_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->src || !a->starts || !a->out || a->B <= 0 || a->S <= 0 || a->C <= 0 || a->length <= 1 || a->L_full < a->length)
         return WJ_ERR_ARG;
     hipLaunchKernelGGL(crop_kernel, dim3(a->B * a->S), dim3(1024), 0, STREAM, *a);

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(wj_colsum_args a, int rows_
 }  // namespace
 
 extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->x || !a->gamma || !a->beta) return WJ_ERR_ARG;
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if (a->in_seg > 0 && a->in_valid <= 0) return WJ_ERR_ARG;
@@ -365,6 +366,7 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
 }
 
 extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->dy || !a->x || !a->gamma || !a->mean || !a->rstd) return WJ_ERR_ARG;
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if ((a->in_seg > 0 && a->in_valid <= 0) || (a->out_seg > 0 && a->out_valid <= 0)) return WJ_ERR_ARG;
@@ -395,6 +397,7 @@ extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
 }
 
 extern "C" int wj_colsum_f32(const wj_colsum_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->x || !a->out || a->M <= 0 || a->N <= 0 || (a->N & 3) || (a->ldx & 3)) return WJ_ERR_ARG;
     launch_colsum_f32((const float*)a->x, a->ldx, a->M, a->N, a->out, nullptr, nullptr, a->N, (hipStream_t)stream);
     WJ_CHECK_LAUNCH();
@@ -402,6 +405,7 @@ extern "C" int wj_colsum_f32(const wj_colsum_args* a, void* stream) {
 }
 
 extern "C" int wj_colsum_bf16(const wj_colsum_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
     if (!a || !a->x || !a->out || a->M <= 0 || a->N <= 0 || (a->N & 7) || (a->ldx & 7)) return WJ_ERR_ARG;
     const int gx = (a->N + 63) / 64;
     int gy = 2048 / gx;
