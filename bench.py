@@ -211,7 +211,8 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t0:.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    note(f"timed region done: {elapsed / args.steps * 1000:.1f} ms/step")
+    note(f"timed region done: {elapsed / args.steps * 1000:.1f} ms/step; side-stream probe (pair / single wait per candidate): "
+         f"{getattr(model._engine, '_stream_probe', None)}")
     roofline = None
     classes = {}
     executed_gflop = None

@@ -235,6 +235,14 @@ typedef struct {
 } wj_gelu_bwd_args;
 int wj_gelu_bwd_bf16(const wj_gelu_bwd_args*, void* stream);
 
+/* One wave that busy-waits for `ticks` s_memtime ticks.  Not compute: the engine uses two of these to find a second HIP
+ * stream that really runs beside the main one (HIP maps streams onto a few hardware queues round-robin; two streams on
+ * one queue serialise -- seen as soon as RCCL had created its own streams first). */
+typedef struct {
+    int64_t ticks;
+} wj_spin_args;
+int wj_spin(const wj_spin_args*, void* stream);
+
 /* buf[rows[i]][0 .. row_bytes) = 0 for i < n_rows (restores the all-zero state of a sparse gradient buffer) */
 typedef struct {
     void* buf;

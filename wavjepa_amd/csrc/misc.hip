@@ -496,7 +496,7 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_attn_bwd_args) WJ_SZ(wj_conv0_fwd_args) WJ_SZ(wj_conv0_bwd_args) WJ_SZ(wj_gelu_bwd_args) WJ_SZ(wj_conv_w_args)
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
-    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args)
+    WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args) WJ_SZ(wj_spin_args)
 #undef WJ_SZ
     return -1;
 }
@@ -515,6 +515,19 @@ extern "C" int wj_gelu_bwd_bf16(const wj_gelu_bwd_args* a, void* stream) {
     if (!a || !a->dpost || !a->pre || !a->dpre || a->n <= 0 || (a->n & 7)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(a->n / 8, 256)), dim3(256), 0, STREAM, (const bf16_t*)a->dpost,
                        (const bf16_t*)a->pre, (bf16_t*)a->dpre, (long)(a->n / 8));
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+__global__ void spin_kernel(long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long)(__builtin_amdgcn_s_memtime() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int wj_spin(const wj_spin_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
+    if (!a || a->ticks < 0 || a->ticks > (1LL << 32)) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, STREAM, (long)a->ticks);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

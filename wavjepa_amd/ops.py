@@ -150,6 +150,11 @@ def gelu_bwd_bf16(dpost: Ptr, pre: Ptr, dpre: Ptr, n: int, *, rows: Ptr = None, 
          n_rows=n_rows, row_elems=row_elems, clear_dpost=int(clear_dpost))
 
 
+def spin(ticks: int, stream: Optional[int] = None) -> None:
+    """One wave busy-waiting for `ticks` s_memtime ticks (stream-concurrency probe)."""
+    _run("wj_spin", "wj_spin_args", stream, ticks=int(ticks))
+
+
 def zero_rows(buf: Ptr, rows: Ptr, *, n_rows: int, row_bytes: int, stream: Optional[int] = None) -> None:
     _run("wj_zero_rows", "wj_zero_rows_args", stream, buf=_p(buf), rows=_p(rows), n_rows=n_rows, row_bytes=row_bytes)
 
