@@ -119,6 +119,35 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
         assert e < 3e-2, (g, e)
 
 
+def test_forward_backward_parity_speech_masks(golden_dir):
+    """The LibriSpeech masker's masks (short, clustered targets; long contexts) through the ragged path."""
+    m, P = build(SMALL)
+    fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    ctx, tgt, vis = (torch.from_numpy(fx[k][:4]) for k in ("ls_ctx", "ls_tgt", "ls_vis"))
+    audio = torch.from_numpy(synth.synth_audio(4, 1, 32159, seed=13)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt, vis)
+    assert m._engine.ragged_step
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(SMALL))
+    lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    num, den = {}, {}
+    for k in names:
+        g = group_of(k)
+        a, b = got[k].grad.double(), P[k].grad.double()
+        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
+    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    print("speech masks: loss", lo, lr_, "grad rel errors per group:", errs)
+    for g, e in errs.items():
+        assert e < 3e-2, (g, e)
+
+
 def test_mask_gather_bit_exact_and_shapes(golden_dir):
     m, P = build(SMALL)
     ctx, tgt, vis = masks(golden_dir, 3)

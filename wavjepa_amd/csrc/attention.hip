@@ -29,30 +29,42 @@ template <int HD> struct Img {
 // All global loads of a thread are issued before its first LDS store (a load->store loop would serialise one HBM/L2
 // round trip per iteration: ~13 of them for a 200 x 64 head).
 template <int HD, int NWAVES, int MT = MAX_TILES>
+struct RowRegs {
+    static constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
+    static constexpr int MAXI = (MT * 16 * CH + NWAVES * 64 - 1) / (NWAVES * 64);
+    uint4 v0[MAXI], v1[MAXI];
+
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ src0, long ld0, const bf16_t* __restrict__ src1, long ld1, int T) {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int idx = threadIdx.x + it * (NWAVES * 64);
+            const int row = idx / CH, c = idx - row * CH;
+            v0[it] = v1[it] = make_uint4(0, 0, 0, 0);
+            if (row < T) {
+                v0[it] = *reinterpret_cast<const uint4*>(src0 + (long)row * ld0 + c * 8);
+                v1[it] = *reinterpret_cast<const uint4*>(src1 + (long)row * ld1 + c * 8);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* img0, char* img1, int KP) const {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int idx = threadIdx.x + it * (NWAVES * 64);
+            const int row = idx / CH, c = idx - row * CH;
+            if (row < KP) {
+                *reinterpret_cast<uint4*>(img0 + row * RS + c * 16) = v0[it];
+                *reinterpret_cast<uint4*>(img1 + row * RS + c * 16) = v1[it];
+            }
+        }
+    }
+};
+
+template <int HD, int NWAVES, int MT = MAX_TILES>
 __device__ __forceinline__ void fill_images2(char* img0, const bf16_t* __restrict__ src0, long ld0, char* img1,
                                              const bf16_t* __restrict__ src1, long ld1, int T, int KP) {
-    constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
-    constexpr int MAXI = (MT * 16 * CH + NWAVES * 64 - 1) / (NWAVES * 64);
-    uint4 v0[MAXI], v1[MAXI];
-#pragma unroll
-    for (int it = 0; it < MAXI; ++it) {
-        const int idx = threadIdx.x + it * (NWAVES * 64);
-        const int row = idx / CH, c = idx - row * CH;
-        v0[it] = v1[it] = make_uint4(0, 0, 0, 0);
-        if (row < T) {
-            v0[it] = *reinterpret_cast<const uint4*>(src0 + (long)row * ld0 + c * 8);
-            v1[it] = *reinterpret_cast<const uint4*>(src1 + (long)row * ld1 + c * 8);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < MAXI; ++it) {
-        const int idx = threadIdx.x + it * (NWAVES * 64);
-        const int row = idx / CH, c = idx - row * CH;
-        if (row < KP) {
-            *reinterpret_cast<uint4*>(img0 + row * RS + c * 16) = v0[it];
-            *reinterpret_cast<uint4*>(img1 + row * RS + c * 16) = v1[it];
-        }
-    }
+    RowRegs<HD, NWAVES, MT> r;
+    r.load(src0, ld0, src1, ld1, T);
+    r.store(img0, img1, KP);
 }
 
 // MFMA operand with k = head-dim: lane (i,g) gets row (rbase+i), d = ks*32 + 8g .. +7, from the LDS image.
@@ -237,6 +249,11 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
     fill_images2<HD, NWB, MT>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
+    // short sequences: phase B's Q / dO rows are fetched NOW (a few registers per thread) and only parked in LDS once phase A
+    // is done with the K / V images -- their global latency hides behind the statistics loop and phase A
+    constexpr bool EARLY = MT <= 8;
+    RowRegs<HD, NWB, MT> nxt;
+    if constexpr (EARLY) nxt.load(qkv, ld, dO, D, T);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
         float l = INFINITY, dl = 0.f, kv = 0.f;
         if (r < T) {
@@ -330,7 +347,8 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
             }
     }
     __syncthreads();
-    fill_images2<HD, NWB, MT>(img0, qkv, ld, img1, dO, D, T, KP);
+    if constexpr (EARLY) nxt.store(img0, img1, KP);
+    else fill_images2<HD, NWB, MT>(img0, qkv, ld, img1, dO, D, T, KP);
     __syncthreads();
 
     // ---- phase B: dK, dV for 16 keys per wave iteration (keys on the lane, queries on the accumulator rows)
