@@ -250,6 +250,9 @@ def main():
                        "step_gemm_gflop_per_clip_executed": None if executed_gflop is None else round(executed_gflop / args.clips_per_gpu, 1)},
             # executed GEMM flops (instrumented step) over the measured step time; NOT the dense-shape flop count
             "model_tflops_per_gpu": None if executed_gflop is None else round(executed_gflop / (elapsed / args.steps) / 1000, 1),
+            # dense model FLOPs exactly as the reference computes them (283.7 GFLOP per clip and step), independent
+            # of the rows the ragged execution does not compute -- the rate a dense-shape implementation would need to keep up
+            "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1),
             "final_loss": round(loss, 5),
             "roofline": roofline,
         }
