@@ -140,7 +140,7 @@ int wj_colsum_f32(const wj_colsum_args*, void* stream);
  * student (jepa.py:397,452, mask = ctx_masks), the predictor (jepa.py:438, mask = ctx_and_target_masks) and the
  * teacher (jepa.py:256-258, no mask).   qkv: bf16 [B][T][3*H*hd] packed q|k|v;  key_mask: u8 [B][T], nonzero =
  * key NOT attended, or NULL;  out: bf16 [B][T][H*hd];  lse: f32 [B][H][T] (log-sum-exp of scaled scores).
- * hd in {32, 64};  T <= 224.
+ * hd in {32, 64};  T <= 416 (three instantiations: <= 128, <= 224, <= 416 tokens).
  * Ragged form (seq_off != NULL): the B sequences are PACKED back to back, sequence b = rows [seq_off[b], seq_off[b+1])
  * of qkv / out / dout / dqkv, every key attended (key_mask must be NULL), T = upper bound of the lengths, and
  * lse: f32 [rows][H].  This is how the student / predictor run on their visible tokens only: a key-masked query row

@@ -27,7 +27,7 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build(cfg, seed=7, teacher_scale=0.97, **kw):
+def build(cfg, seed=7, teacher_scale=0.97, seconds=2.01, tokens=200, **kw):
     from wavjepa_amd.extractors import ConvFeatureExtractor
     from wavjepa_amd.jepa import JEPA
     from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
@@ -38,15 +38,15 @@ def build(cfg, seed=7, teacher_scale=0.97, **kw):
              transformer_decoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_dec"]),
              transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_dec"], nhead=cfg["h_dec"]),
              lr=4e-4, adam_betas=(0.9, 0.98), adam_weight_decay=0.04, average_top_k_layers=cfg["top_k"],
-             process_audio_seconds=2.01, nr_samples_per_audio=2, **kw)
+             process_audio_seconds=seconds, nr_samples_per_audio=2, **kw)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = synth.synth_state_dict(shapes, seed=seed)
     for k in list(sd):
         if k.startswith("teacher_encoder.") and k.endswith("weight") and sd[k].ndim == 2:
             sd[k] = (sd[k] * np.float32(teacher_scale)).astype(np.float32)
     sd = {k: torch.from_numpy(v) for k, v in sd.items()}
-    sd["pos_encoding_encoder"] = J.sincos_positions(cfg["d_enc"], 200)
-    sd["pos_encoding_decoder"] = J.sincos_positions(cfg["d_dec"], 200)
+    sd["pos_encoding_encoder"] = J.sincos_positions(cfg["d_enc"], tokens)
+    sd["pos_encoding_decoder"] = J.sincos_positions(cfg["d_dec"], tokens)
     m.load_state_dict(sd)
     P = {k: v.clone().to(dev()) for k, v in sd.items()}
     return m.to(dev()), P
@@ -144,6 +144,40 @@ def test_forward_backward_parity_speech_masks(golden_dir):
         den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
     errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
     print("speech masks: loss", lo, lr_, "grad rel errors per group:", errs)
+    for g, e in errs.items():
+        assert e < 3e-2, (g, e)
+
+
+@pytest.mark.parametrize("ragged", [True, False])
+def test_forward_backward_parity_400_tokens(golden_dir, ragged):
+    """4.01 s clips (64 160 samples -> 400 tokens; SURVEY 8(f1) shapes, bf16): teacher attention over 400 tokens, ragged or
+    dense student / predictor, against the oracle."""
+    m, P = build(SMALL, seconds=4.01, tokens=400)
+    assert m.total_patches == 400 and m.target_length == 64160
+    m._ensure_engine().ragged = ragged
+    fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    ctx, tgt, vis = (torch.from_numpy(fx[k][:3]) for k in ("as400_ctx", "as400_tgt", "as400_vis"))
+    audio = torch.from_numpy(synth.synth_audio(3, 1, 64160, seed=17)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt, vis)
+    assert m._engine.ragged_step == ragged
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(SMALL))
+    lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
+    assert rel(out["targets"].float(), ref["targets"].float()) < 1e-2
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    num, den = {}, {}
+    for k in names:
+        g = group_of(k)
+        a, b = got[k].grad.double(), P[k].grad.double()
+        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
+    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    print("400 tokens, ragged" if ragged else "400 tokens, dense", "loss", lo, lr_, "grad rel errors per group:", errs)
     for g, e in errs.items():
         assert e < 3e-2, (g, e)
 

@@ -286,7 +286,8 @@ def ref_attention(qkv, H, mask):
     return (p @ v).permute(0, 2, 1, 3).reshape(B, T, D), lse
 
 
-@pytest.mark.parametrize("B,T,H,hd", [(3, 200, 12, 64), (4, 200, 12, 32), (2, 49, 4, 64), (2, 24, 2, 32), (1, 224, 2, 64)])
+@pytest.mark.parametrize("B,T,H,hd", [(3, 200, 12, 64), (4, 200, 12, 32), (2, 49, 4, 64), (2, 24, 2, 32), (1, 224, 2, 64),
+                                      (2, 400, 12, 64), (2, 400, 12, 32), (1, 416, 2, 64), (2, 225, 2, 32)])
 def test_attention_fwd_bwd(ops, B, T, H, hd):
     D = H * hd
     qkv = rnd(B, T, 3 * D, dtype=torch.bfloat16, seed=30)

@@ -15,7 +15,8 @@
 
 namespace {
 
-constexpr int MAX_TILES = 14;  // 16-row tiles: T <= 224
+constexpr int MAX_TILES = 14;  // 16-row tiles of the default instantiation: T <= 224
+constexpr int MAX_TILES_LONG = 26;  // T <= 416 (4.01 s clips -> 400 tokens): K + V images of a 64-wide head = 133 KB of LDS
 constexpr int NWB64 = 4, NWB32 = 4;   // backward waves per workgroup (more waves measured slower: 339 -> 439 us at hd 64)
 constexpr int NWF_LONG = 7;    // forward, T > 128: 13 query tiles over 7 waves (2,2,2,2,2,2,1) instead of 4 (4,3,3,3)
 constexpr int NWF_SHORT = 4;   // forward, T <= 128 (ragged student / predictor): <= 2 tiles per wave, twice the workgroups per CU
@@ -115,7 +116,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // ------------------------------------------------------------------------------------------------ forward
 // MT = most 16-row tiles a sequence may have (14: T <= 224; 8: T <= 128, fewer live registers -> more waves per SIMD)
 template <int HD, int NWF, int MT>
-__global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : 6) void attn_fwd_kernel(wj_attn_fwd_args a) {
+__global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 : 6) : 2)) void attn_fwd_kernel(wj_attn_fwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, D = H * HD;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : 6) void attn_fwd_kernel(wj
 
 // ------------------------------------------------------------------------------------------------ backward
 template <int HD, int NWB, int MT>
-__global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj_attn_bwd_args a) {
+__global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void attn_bwd_kernel(wj_attn_bwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, D = H * HD;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_kernel(wj
     fill_images2<HD, NWB, MT>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
     // short sequences: phase B's Q / dO rows are fetched NOW (a few registers per thread) and only parked in LDS once phase A
     // is done with the K / V images -- their global latency hides behind the statistics loop and phase A
-    constexpr bool EARLY = MT <= 8;
+    constexpr bool EARLY = MT <= 8 && HD == 32;   // (the 64-wide head has no registers to spare at 3 waves per SIMD)
     RowRegs<HD, NWB, MT> nxt;
     if constexpr (EARLY) nxt.load(qkv, ld, dO, D, T);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
@@ -456,7 +457,7 @@ int set_lds(K kern, int bytes) {
 extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->qkv || !a->out) return WJ_ERR_ARG;
-    if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
+    if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES_LONG * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     const int KP = ((a->T + 31) / 32) * 32;
@@ -464,10 +465,14 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
     dim3 grid(a->B * a->H);
     hipStream_t st = (hipStream_t)stream;
     static int once = set_lds(attn_fwd_kernel<64, NWF_LONG, 14>, 2 * 224 * 160 + 224 * 4) | set_lds(attn_fwd_kernel<32, NWF_LONG, 14>, 2 * 224 * 96 + 224 * 4) |
-                      set_lds(attn_fwd_kernel<64, NWF_SHORT, 8>, 2 * 128 * 160 + 128 * 4) | set_lds(attn_fwd_kernel<32, NWF_SHORT, 8>, 2 * 128 * 96 + 128 * 4);
+                      set_lds(attn_fwd_kernel<64, NWF_SHORT, 8>, 2 * 128 * 160 + 128 * 4) | set_lds(attn_fwd_kernel<32, NWF_SHORT, 8>, 2 * 128 * 96 + 128 * 4) |
+                      set_lds(attn_fwd_kernel<64, NWF_LONG, 26>, 2 * 416 * 160 + 416 * 4) | set_lds(attn_fwd_kernel<32, NWF_LONG, 26>, 2 * 416 * 96 + 416 * 4);
     (void)once;
     const bool shortseq = a->T <= 128;
-    if (a->hd == 64) {
+    if (a->T > MAX_TILES * 16) {     // 225 .. 416 tokens
+        if (a->hd == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_LONG, 26>), grid, dim3(NWF_LONG * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_LONG, 26>), grid, dim3(NWF_LONG * 64), lds, st, *a);
+    } else if (a->hd == 64) {
         if (shortseq) hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_SHORT, 8>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_LONG, 14>), grid, dim3(NWF_LONG * 64), lds, st, *a);
     } else {
@@ -481,7 +486,7 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
 extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->dqkv) return WJ_ERR_ARG;
-    if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
+    if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES_LONG * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
     if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
     if (a->dbias && !a->dbias_ws) return WJ_ERR_ARG;
@@ -490,9 +495,14 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     dim3 grid(a->B * a->H);
     hipStream_t st = (hipStream_t)stream;
     static int once = set_lds(attn_bwd_kernel<64, NWB64, 14>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4) |
-                      set_lds(attn_bwd_kernel<32, NWB32, 14>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4);
+                      set_lds(attn_bwd_kernel<32, NWB32, 14>, 2 * 224 * 96 + 3 * 224 * 4 + 3 * 32 * 4) |
+                      set_lds(attn_bwd_kernel<64, NWB64, 26>, 2 * 416 * 160 + 3 * 416 * 4 + 3 * 64 * 4) |
+                      set_lds(attn_bwd_kernel<32, NWB32, 26>, 2 * 416 * 96 + 3 * 416 * 4 + 3 * 32 * 4);
     (void)once;
-    if (a->T <= 128) {          // ragged student / predictor: at most 8 tiles (6 or 8 waves per workgroup measured 1.5-2x slower)
+    if (a->T > MAX_TILES * 16) {     // 225 .. 416 tokens
+        if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 26>), grid, dim3(NWB64 * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 26>), grid, dim3(NWB32 * 64), lds, st, *a);
+    } else if (a->T <= 128) {          // ragged student / predictor: at most 8 tiles (6 or 8 waves per workgroup measured 1.5-2x slower)
         if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 8>), grid, dim3(NWB64 * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 8>), grid, dim3(NWB32 * 64), lds, st, *a);
     } else if (a->hd == 64) {
