@@ -378,6 +378,15 @@ typedef struct {
 int wj_masked_mse(const wj_mse_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Workspace sizes.  The library never allocates: entry points that need scratch take a `workspace` pointer, and this
+ * query tells the caller how many BYTES the call described by the SAME argument struct needs (pointers in it are
+ * ignored).  `fn` is the entry point's name: "wj_layernorm_bwd", "wj_attn_bwd" (its dbias_ws), "wj_conv0_gn_gelu_fwd",
+ * "wj_conv0_gn_gelu_bwd", "wj_masked_mse", "wj_grad_sumsq".  Returns 0 for entry points without scratch, -1 for an unknown
+ * name or NULL arguments.
+ * -----------------------------------------------------------------------------------------------------------*/
+int64_t wj_workspace_bytes(const char* fn, const void* args);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Optimiser-side fused kernels over FLAT parameter storage.
  * -----------------------------------------------------------------------------------------------------------*/
 /* teacher = r * teacher + (1 - r) * student (f32, jepa.py:193-198); also refreshes teacher_bf16 when non-NULL. */

@@ -50,7 +50,7 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.wj_gemm_bf16(ctypes.byref(a), None) == -1
     b = _abi.STRUCTS["wj_attn_fwd_args"]()
     b.qkv = b.out = 16
-    b.B, b.T, b.H, b.hd, b.mask_group = 1, 300, 2, 64, 1              # T > 224
+    b.B, b.T, b.H, b.hd, b.mask_group = 1, 500, 2, 64, 1              # T > 416
     assert lib.wj_attn_fwd(ctypes.byref(b), None) == -1
     b.T, b.hd = 200, 48
     assert lib.wj_attn_fwd(ctypes.byref(b), None) == -3               # unsupported head dim
@@ -179,6 +179,18 @@ def test_flat_params_and_gradient_bucket_tiling():
     assert total == flat.n
     # student-encoder slice mirrors the teacher buffer (single-kernel EMA)
     assert flat.enc_numel == flat.tn
+
+
+def test_workspace_query():
+    """wj_workspace_bytes: the caller sizes every scratch buffer from the library (no compute, runs without a GPU)."""
+    from wavjepa_amd import ops
+    assert ops.workspace_bytes("wj_layernorm_bwd", D=768) == 1536 * 3 * 768 * 4
+    assert ops.workspace_bytes("wj_attn_bwd", B=1024, H=12, hd=32) == 1024 * 3 * 384 * 4
+    assert ops.workspace_bytes("wj_conv0_gn_gelu_bwd", N=256, C=512, C_in=1, k=10) == 256 * 512 * 12 * 4
+    assert ops.workspace_bytes("wj_masked_mse", B=256, G=4, T=200) == (2 + 204800) * 4
+    from wavjepa_amd import _abi
+    lib = _abi.load()
+    assert lib.wj_workspace_bytes(b"wj_gemm_bf16", b"x") == 0 and lib.wj_workspace_bytes(b"nope", b"x") == -1
 
 
 def test_conv_geometry_and_mask_plan():

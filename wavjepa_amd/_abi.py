@@ -113,12 +113,24 @@ def load():
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     if lib.wj_abi_version() != ENUMS.get("WJ_ABI_VERSION", lib.wj_abi_version()):
         pass
+    if not hasattr(lib, "wj_workspace_bytes"):
+        raise WavJepaHipError(f"{LIB_PATH} does not export wj_workspace_bytes; rebuild it")
+    lib.wj_workspace_bytes.restype = ctypes.c_int64
+    lib.wj_workspace_bytes.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
     for name, cls in STRUCTS.items():
         want = lib.wj_struct_size(name.encode())
         if want != ctypes.sizeof(cls):
             raise WavJepaHipError(f"struct {name}: header mirror is {ctypes.sizeof(cls)} bytes, library says {want}")
     _lib = lib
     return lib
+
+
+def workspace_bytes(fn_name: str, args_struct) -> int:
+    """Scratch bytes the call `fn_name(args_struct)` needs (pointers in the struct are ignored)."""
+    n = int(load().wj_workspace_bytes(fn_name.encode(), ctypes.byref(args_struct)))
+    if n < 0:
+        raise WavJepaHipError(f"wj_workspace_bytes: unknown entry point {fn_name}")
+    return n
 
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}

@@ -501,6 +501,35 @@ extern "C" int wj_struct_size(const char* name) {
     return -1;
 }
 
+extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
+    if (!fn || !args) return -1;
+    if (!strcmp(fn, "wj_layernorm_bwd")) return 1536LL * 3 * ((const wj_ln_bwd_args*)args)->D * 4;
+    if (!strcmp(fn, "wj_attn_bwd")) {
+        const wj_attn_bwd_args* a = (const wj_attn_bwd_args*)args;
+        return (int64_t)a->B * 3 * a->H * a->hd * 4;
+    }
+    if (!strcmp(fn, "wj_conv0_gn_gelu_fwd")) {
+        const wj_conv0_fwd_args* a = (const wj_conv0_fwd_args*)args;
+        return (int64_t)a->N * a->C * 2 * 4;
+    }
+    if (!strcmp(fn, "wj_conv0_gn_gelu_bwd")) {
+        const wj_conv0_bwd_args* a = (const wj_conv0_bwd_args*)args;
+        return (int64_t)a->N * a->C * (2 + a->C_in * a->k) * 4;
+    }
+    if (!strcmp(fn, "wj_masked_mse")) {
+        const wj_mse_args* a = (const wj_mse_args*)args;
+        return (2 + (int64_t)a->B * a->G * a->T) * 4;
+    }
+    if (!strcmp(fn, "wj_grad_sumsq")) return 1024 * 4;
+    static const char* const none[] = {"wj_gemm_bf16", "wj_layernorm_fwd", "wj_colsum_bf16", "wj_colsum_f32", "wj_attn_fwd", "wj_gelu_bwd_bf16",
+        "wj_conv_weight_layout", "wj_add_pos", "wj_mask_gather_rows", "wj_mask_scatter_fill_pos", "wj_mask_scatter_fill_pos_bwd",
+        "wj_unmask_rows_f32", "wj_instnorm_accumulate", "wj_instnorm_mean", "wj_ema_update", "wj_adamw_step", "wj_cast_f32_to_bf16",
+        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin"};
+    for (const char* n : none)
+        if (!strcmp(fn, n)) return 0;
+    return -1;
+}
+
 extern "C" int wj_gelu_bwd_bf16(const wj_gelu_bwd_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (a && a->rows) {

@@ -387,7 +387,7 @@ class JepaEngine:
         self.tea_keep = [torch.empty(M, c.d_enc, dtype=f32, device=dev) for _ in range(nkeep)]
         self.tea_stats = torch.zeros(max(nkeep, 1), N, 2, dtype=f32, device=dev)
         self.loss = torch.zeros(2, dtype=f32, device=dev)
-        self.mse_ws = torch.empty(2 + Mp, dtype=f32, device=dev)
+        self.mse_ws = torch.empty(ops.workspace_bytes("wj_masked_mse", B=N, G=G, T=T) // 4, dtype=f32, device=dev)
         # backward scratch, one set per stack width
         self.bw = {}
         for tag, (m, d) in dict(enc=(M, c.d_enc), dec=(Mp, c.d_dec)).items():
@@ -401,7 +401,10 @@ class JepaEngine:
                 dqkv=[torch.empty(m, 3 * d, dtype=bf, device=dev) for _ in range(2)],
                 done=[torch.cuda.Event() for _ in range(2)], used=[False, False])
         # scratch for two-stage parameter-gradient reductions (LayerNorm: [1536][3][D]; attention in_proj bias: [B][3D])
-        self.red_ws = torch.empty(max(1536 * 3 * max(c.d_enc, c.d_dec, C), N * G * 3 * c.d_dec, N * 3 * c.d_enc), dtype=f32, device=dev)
+        red_bytes = max(ops.workspace_bytes("wj_layernorm_bwd", D=max(c.d_enc, c.d_dec, C)),
+                        ops.workspace_bytes("wj_attn_bwd", B=N * G, H=c.h_dec, hd=c.d_dec // c.h_dec),
+                        ops.workspace_bytes("wj_attn_bwd", B=N, H=c.h_enc, hd=c.d_enc // c.h_enc))
+        self.red_ws = torch.empty(red_bytes // 4, dtype=f32, device=dev)
         self.dpreds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
         self.d_cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)
         self.d_ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)

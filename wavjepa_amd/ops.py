@@ -62,6 +62,16 @@ def require_gpu() -> None:
         raise _abi.WavJepaHipError("wavjepa_amd needs a HIP device (MI355X); there is no CPU fallback")
 
 
+def workspace_bytes(fn: str, **dims) -> int:
+    """Scratch bytes entry point `fn` needs for the given dimensions (fields of its argument struct), from the library."""
+    struct_name = {"wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
+                   "wj_conv0_gn_gelu_bwd": "wj_conv0_bwd_args", "wj_masked_mse": "wj_mse_args", "wj_grad_sumsq": "wj_sumsq_args"}[fn]
+    a = STRUCTS[struct_name]()
+    for k, v in dims.items():
+        setattr(a, k, v)
+    return _abi.workspace_bytes(fn, a)
+
+
 # ---------------------------------------------------------------------------------------------------------- GEMM
 def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, a_trans: int = 0,
          b_trans: int = 0, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, aux: Ptr = None, split_k: int = 1,
