@@ -208,7 +208,6 @@ class JepaEngine:
         self.sparse_conv = _os.environ.get("WJ_SPARSE_CONV", "1") != "0" and all(k >= st for _, k, st in cfg.conv_spec[1:])
         self._conv_grads_dirty = False
         self.side = self._pick_side_stream() if self.use_side else torch.cuda.Stream(device=self.dev)
-        self._ev = [torch.cuda.Event() for _ in range(8)]
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
         self._bind_params()
         self._conv_w: Dict[str, torch.Tensor] = {}
