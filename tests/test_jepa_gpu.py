@@ -87,7 +87,9 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     ref32 = J.jepa_forward({k: v.detach() for k, v in P.items()}, audio.float(), ctx.to(dev()), tgt.to(dev()), vis.to(dev()),
                            mode="fp32", **oracle_kw(cfg))
     report = {k: rel(out[k].float(), ref[k].float()) for k in ("local_features", "contextual_features", "targets")}
-    seen = (~vis).reshape(-1, vis.shape[-1]).to(dev())            # predictor rows that exist on a ragged step
+    # predictor rows whose output exists: on a ragged step the target rows (the last layer drops the context rows after its
+    # attention: nothing reads their outputs); on a dense step every row
+    seen = (tgt if ragged else ~vis).reshape(-1, vis.shape[-1]).to(dev())
     assert out["preds"].shape == ref["preds"].shape
     report["preds"] = rel(out["preds"][seen].float(), ref["preds"][seen].float())
     if ragged:

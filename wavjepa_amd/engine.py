@@ -57,6 +57,12 @@ class MaskPlan:
     dec_off: Optional[torch.Tensor] = None    # int32 [N*G+1]
     dec_map: Optional[torch.Tensor] = None    # int32 [N*G*T]   packed row of a dense position or -1
     n_dec: int = 0
+    # predictor rows whose OUTPUT is used (targets): after the last layer's attention only these go on (context rows of the
+    # last layer serve as keys / values only)
+    tgt_rows: Optional[torch.Tensor] = None   # int32 [n_tgt]  packed predictor row of every target, ascending
+    tgt_inv: Optional[torch.Tensor] = None    # int32 [n_dec]  position in tgt_rows or -1
+    tgt_dense: Optional[torch.Tensor] = None  # int32 [n_tgt]  dense (b*G+g)*T+t of those rows (loss row list)
+    n_tgt: int = 0
     max_enc: int = 0                          # longest context / visible sequence (attention length bound)
     max_dec: int = 0
     ragged_ok: bool = False                   # False when a target position is key-masked: the dense path must be used
@@ -86,6 +92,14 @@ def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
     dec_map[dec_rows] = np.arange(dec_rows.size, dtype=np.int32)
     ragged_ok = (tgt_np.reshape(vis_np.shape).shape == vis_np.shape
                  and not bool(np.any(tgt_np.reshape(vis_np.shape) & vis_np)))   # every target row is also a key
+    if ragged_ok:
+        is_tgt = tgt_np.reshape(-1)[dec_rows]                 # per packed predictor row
+        tgt_rows = np.flatnonzero(is_tgt).astype(np.int32)
+        tgt_inv = np.full(dec_rows.size, -1, dtype=np.int32)
+        tgt_inv[tgt_rows] = np.arange(tgt_rows.size, dtype=np.int32)
+        tgt_dense = dec_rows[tgt_rows]
+    else:
+        tgt_rows = tgt_inv = tgt_dense = np.zeros(0, np.int32)
 
     def up(a, dt):
         return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device, non_blocking=True)
@@ -93,6 +107,8 @@ def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
     return MaskPlan(up(ctx_np, np.uint8), up(tgt_np, np.uint8), up(vis_np, np.uint8), up(keep_np, np.int32), up(inv_np, np.int32),
                     int(keep_np.size), enc_off=up(enc_off, np.int32), dec_rows=up(dec_rows, np.int32),
                     dec_off=up(dec_off, np.int32), dec_map=up(dec_map, np.int32), n_dec=int(dec_rows.size),
+                    tgt_rows=up(tgt_rows, np.int32), tgt_inv=up(tgt_inv, np.int32), tgt_dense=up(tgt_dense, np.int32),
+                    n_tgt=int(tgt_rows.size),
                     max_enc=int(ctx_len.max()) if ctx_len.size else 0, max_dec=int(dec_len.max()) if dec_len.size else 0,
                     ragged_ok=ragged_ok, ctx_np=ctx_np)
 
@@ -207,6 +223,9 @@ class JepaEngine:
         # conv backward over the active rows only (needs a ragged step and k >= stride in every GEMM conv layer)
         self.sparse_conv = _os.environ.get("WJ_SPARSE_CONV", "1") != "0" and all(k >= st for _, k, st in cfg.conv_spec[1:])
         self._conv_grads_dirty = False
+        # last predictor layer: after its attention only the target rows go on (WJ_TRIM_TAIL=0: every visible row)
+        self.trim_tail = _os.environ.get("WJ_TRIM_TAIL", "1") != "0"
+        self.tail = None
         self.side = self._pick_side_stream() if self.use_side else torch.cuda.Stream(device=self.dev)
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
         self._bind_params()
@@ -373,6 +392,9 @@ class JepaEngine:
         self.ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)       # gathered context rows (<= M)
         self.enc_in = torch.empty(M, c.d_enc, dtype=f32, device=dev)      # ragged: local features of the context rows
         self.enc_in_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        self.tail_o = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)      # last predictor layer: target rows of o / x_in / do
+        self.tail_x = torch.empty(Mp, c.d_dec, dtype=f32, device=dev)
+        self.tail_do = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
         self.cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)           # contextual_features
         self.dec_in = torch.empty(Mp, c.d_dec, dtype=f32, device=dev)
         self.dec_in_b = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
@@ -413,17 +435,26 @@ class JepaEngine:
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
                    mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None, save: bool = True,
-                   x2_out: Optional[torch.Tensor] = None, x2_stats: Optional[torch.Tensor] = None) -> None:
+                   x2_out: Optional[torch.Tensor] = None, x2_stats: Optional[torch.Tensor] = None,
+                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> None:
         """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1)))).
         `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask.
-        save=False (teacher / inference): nothing is kept for a backward (no gelu' output, no softmax statistics)."""
+        save=False (teacher / inference): nothing is kept for a backward (no gelu' output, no softmax statistics).
+        sub = (rows int32 [Ms], inverse int32 [M], Ms): only these rows continue after the attention (the last predictor layer:
+        context rows are keys / values there and nothing reads their outputs)."""
         eps = self.cfg.ln_eps
         ops.gemm(xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, lda=D, ldb=D, ldc=3 * D, bias=w.bqkv)
         if seq is not None:
             ops.attn_fwd(a.qkv, a.o, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], lse=a.lse if save else None)
         else:
             ops.attn_fwd(a.qkv, a.o, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, lse=a.lse if save else None)
-        ops.gemm(a.o, w.wo, a.p, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, bias=w.bo)
+        o_in = a.o
+        if sub is not None:
+            rows, _, M = sub                                   # M: the rows that go on
+            ops.mask_gather_rows(a.o, rows, self.tail_o, n_rows=M, D=D, elem_bytes=2)
+            ops.mask_gather_rows(x_in, rows, self.tail_x, n_rows=M, D=D, elem_bytes=4)
+            o_in, x_in = self.tail_o, self.tail_x
+        ops.gemm(o_in, w.wo, a.p, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, bias=w.bo)
         ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1)
         if save:
             ops.gemm(a.x1b, w.w1, a.h, C2=a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2)
@@ -460,7 +491,8 @@ class JepaEngine:
 
     def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dx_out: torch.Tensor,
                    M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int,
-                   seq: Optional[Tuple[torch.Tensor, int]] = None) -> None:
+                   seq: Optional[Tuple[torch.Tensor, int]] = None,
+                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> None:
         """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer.
         The four weight-gradient GEMMs only need (dY, X) and nothing downstream needs them before the optimiser: they run on
         the side stream while the main stream continues the dgrad chain."""
@@ -468,6 +500,10 @@ class JepaEngine:
         dsb2, dsb1, dh, dqkv = bw["dsb2"][parity], bw["dsb1"][parity], bw["dh"][parity], bw["dqkv"][parity]
         if self.use_side and bw["used"][parity]:
             torch.cuda.current_stream().wait_event(bw["done"][parity])   # side stream finished reading this parity's buffers
+        Mall, x_ln1, o_in = M, x_in, a.o
+        if sub is not None:              # dy holds the sub-rows only; everything up to the attention works on them
+            M = sub[2]
+            x_ln1, o_in = self.tail_x, self.tail_o
         ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb2, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2,
                           workspace=self.red_ws)
         ops.gemm(dsb2, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
@@ -478,22 +514,29 @@ class JepaEngine:
             self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
         self._on_side(wgrad_mlp)
         ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
-        ops.layernorm_bwd(dx1, x_in, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb1, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
+        ops.layernorm_bwd(dx1, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb1, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
                           workspace=self.red_ws)
-        ops.gemm(dsb1, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+        ds_all = ds
+        if sub is None:
+            ops.gemm(dsb1, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+        else:                             # back to all rows: zero gradient where no output was used
+            ops.gemm(dsb1, w.wo, self.tail_do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+            ops.unmask_rows_f32(self.tail_do, sub[1], do, M=Mall, D=D, dst_is_bf16=True)
+            ops.unmask_rows_f32(ds, sub[1], dx1, M=Mall, D=D, src_is_f32=True)       # dx1 is free again: residual gradient
+            ds_all = dx1
         if seq is not None:
             ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], dbias=w.gbqkv, dbias_ws=self.red_ws)
         else:
             ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
 
         def wgrad_attn():
-            self._wgrad(dsb1, a.o, w.gwo, D, D, M)
-            self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, M)
+            self._wgrad(dsb1, o_in, w.gwo, D, D, M)
+            self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, Mall)
             if self.use_side:
                 bw["done"][parity].record(self.side)
                 bw["used"][parity] = True
         self._on_side(wgrad_attn)
-        ops.gemm(dqkv, w.wqkv, dx_out, M=M, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
+        ops.gemm(dqkv, w.wqkv, dx_out, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds_all)
 
     # ------------------------------------------------------------------------------------------------ front-end
     def _frontend(self, audio: torch.Tensor) -> None:
@@ -571,30 +614,44 @@ class JepaEngine:
             ops.mask_scatter_fill_pos(self.cf, plan.inv, f.ptr32("mask_token"), self.pos_dec, B=N, T=T, D=Dd, G=G,
                                       out_f32=self.dec_in, out_bf16=self.dec_in_b)
         x, xb = self.dec_in, self.dec_in_b
-        for w, a in zip(self.dec_layers, self.dec_acts):
-            self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq)
+        self.tail = (plan.tgt_rows, plan.tgt_inv, plan.n_tgt) if (self.ragged_step and self.trim_tail and plan.n_tgt > 0) else None
+        Mo = Md                          # rows that leave the predictor
+        for i, (w, a) in enumerate(zip(self.dec_layers, self.dec_acts)):
+            last = i == c.l_dec - 1
+            self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq, sub=self.tail if last else None)
             x, xb = a.x2, a.x2b
-        ops.layernorm_fwd(x, f.ptr32("decoder.norm.weight"), f.ptr32("decoder.norm.bias"), M=Md, D=Dd, eps=c.norm_eps,
+        if self.tail is not None:
+            Mo = plan.n_tgt
+        ops.layernorm_fwd(x, f.ptr32("decoder.norm.weight"), f.ptr32("decoder.norm.bias"), M=Mo, D=Dd, eps=c.norm_eps,
                           y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr)
-        ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Md, N=De, K=Dd, lda=Dd, ldb=Dd,
+        ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Mo, N=De, K=Dd, lda=Dd, ldb=Dd,
                  ldc=De, bias=f.ptr32("decoder_to_encoder_mapper.bias"))
         self._join_side()               # teacher targets (side stream) are needed by the loss
         self._mse(None, None)
 
     def _mse(self, dpreds, gscale_ptr) -> None:
         c, plan = self.cfg, self.plan
-        rows = dict(rows=plan.dec_rows, n_rows=plan.n_dec) if self.ragged_step else {}
+        if self.ragged_step and self.tail is not None:
+            rows = dict(rows=plan.tgt_dense, n_rows=plan.n_tgt)          # preds hold the target rows only
+        else:
+            rows = dict(rows=plan.dec_rows, n_rows=plan.n_dec) if self.ragged_step else {}
         ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=self.N, G=c.groups, T=self.T, D=c.d_enc,
                        dpreds=dpreds, gscale_ptr=gscale_ptr, **rows)
 
     def dense_preds(self) -> torch.Tensor:
         """Predictions as the reference shapes them, bf16 [N*G, T, d_enc].  On a ragged step only the visible rows were
-        computed; the others (zero loss weight on the reference, jepa.py:356) read 0."""
+        computed (with the trimmed last layer: only the target rows); the others (zero loss weight on the reference,
+        jepa.py:356) read 0."""
         N, G, T, De = self.N, self.cfg.groups, self.T, self.cfg.d_enc
         if not self.ragged_step:
             return self.preds.view(N * G, T, De)
         out = torch.empty(N * G * T, De, dtype=torch.bfloat16, device=self.dev)
-        ops.unmask_rows_f32(self.preds, self.plan.dec_map, out, M=N * G * T, D=De, src_is_f32=False, dst_is_bf16=True)
+        if self.tail is not None:        # preds hold the target rows only: dense position -> packed row -> target row
+            inv = torch.full((N * G * T,), -1, dtype=torch.int32, device=self.dev)
+            inv[self.plan.tgt_dense.long()] = torch.arange(self.plan.n_tgt, dtype=torch.int32, device=self.dev)
+        else:
+            inv = self.plan.dec_map
+        ops.unmask_rows_f32(self.preds, inv, out, M=N * G * T, D=De, src_is_f32=False, dst_is_bf16=True)
         return out.view(N * G, T, De)
 
     def _teacher_targets(self) -> None:
@@ -648,17 +705,19 @@ class JepaEngine:
         self._mse(self.dpreds, gscale_ptr if gscale_ptr else None)
         bw = self.bw["dec"]
         # decoder_to_encoder_mapper
-        ops.colsum_bf16(self.dpreds, f.gptr("decoder_to_encoder_mapper.bias"), M=Md, N=De, ldx=De)
-        self._wgrad(self.dpreds, self.dec_out_b, f.gptr("decoder_to_encoder_mapper.weight"), De, Dd, Md)
-        ops.gemm(self.dpreds, f.ptr16("decoder_to_encoder_mapper.weight"), bw["dx1"], M=Md, N=Dd, K=De, lda=De, ldb=Dd, ldc=Dd,
+        Mo = plan.n_tgt if (rag and self.tail is not None) else Md       # rows that left the predictor
+        ops.colsum_bf16(self.dpreds, f.gptr("decoder_to_encoder_mapper.bias"), M=Mo, N=De, ldx=De)
+        self._wgrad(self.dpreds, self.dec_out_b, f.gptr("decoder_to_encoder_mapper.weight"), De, Dd, Mo)
+        ops.gemm(self.dpreds, f.ptr16("decoder_to_encoder_mapper.weight"), bw["dx1"], M=Mo, N=Dd, K=De, lda=De, ldb=Dd, ldc=Dd,
                  b_trans=1, epilogue=ops.EPI_ADD_F32)
         last = self.dec_acts[-1]
-        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Md, D=Dd, ds_f32=bw["dy"],
+        ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Mo, D=Dd, ds_f32=bw["dy"],
                           dgamma=f.gptr("decoder.norm.weight"), dbeta=f.gptr("decoder.norm.bias"), workspace=self.red_ws)
         dy = bw["dy"]
         for i in range(c.l_dec - 1, -1, -1):
             x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
-            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Md, Dd, c.h_dec, N * G, plan.vis_u8, bw, i & 1, dseq)
+            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Md, Dd, c.h_dec, N * G, plan.vis_u8, bw, i & 1, dseq,
+                            sub=self.tail if (rag and i == c.l_dec - 1) else None)
         n_ctx = plan.n_ctx
         ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
                                       rowmap=plan.dec_map if rag else None)
