@@ -27,11 +27,11 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build(cfg, seed=7, teacher_scale=0.97, seconds=2.01, tokens=200, **kw):
+def build(cfg, seed=7, teacher_scale=0.97, seconds=2.01, tokens=200, in_channels=1, **kw):
     from wavjepa_amd.extractors import ConvFeatureExtractor
     from wavjepa_amd.jepa import JEPA
     from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
-    ext = ConvFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=1)
+    ext = ConvFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=in_channels)
     m = JEPA(feature_extractor=ext,
              transformer_encoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_enc"]),
              transformer_encoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_enc"], nhead=cfg["h_enc"]),
@@ -182,6 +182,27 @@ def test_forward_backward_parity_400_tokens(golden_dir, ragged):
     print("400 tokens, ragged" if ragged else "400 tokens, dense", "loss", lo, lr_, "grad rel errors per group:", errs)
     for g, e in errs.items():
         assert e < 3e-2, (g, e)
+
+
+def test_forward_backward_parity_two_channel_audio(golden_dir):
+    """Binaural input through the 2-channel first conv (`in_channels=2`, 20 taps in conv0)."""
+    m, P = build(SMALL, in_channels=2)
+    ctx, tgt, vis = masks(golden_dir, 3)
+    audio = torch.from_numpy(synth.synth_audio(3, 2, 32159, seed=19)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt, vis)
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(SMALL))
+    lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
+    assert rel(out["local_features"].float(), ref["local_features"].float()) < 1e-2
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    for k in ("extract_audio.cnn.0.0.weight", "extract_audio.cnn.0.2.weight", "extract_audio.cnn.1.0.weight"):
+        e = rel(got[k].grad.float(), P[k].grad.float())
+        assert e < 3e-2, (k, e)
 
 
 def test_mask_gather_bit_exact_and_shapes(golden_dir):
