@@ -3,7 +3,8 @@
 import csv, glob, os, re, sys
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-for d in sys.argv[1:]:
+FILTER = [a[2:] for a in sys.argv[1:] if a.startswith("k=")] or ["gemm3"]      # k=<substring> selects kernels (default: the GEMM)
+for d in [a for a in sys.argv[1:] if not a.startswith("k=")]:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
@@ -11,7 +12,7 @@ for d in sys.argv[1:]:
             a = acc[k][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
 for k, cs in acc.items():
-    if "gemm3" not in k:
+    if not any(t in k for t in FILTER):
         continue
     print(k)
     w = cs.get("SQ_WAVE_CYCLES", [1, 1.0])
