@@ -335,6 +335,32 @@ def test_inference_representation(golden_dir):
     assert rep.shape == (2, 200, 128) and rel(rep[:, :150], ref[:, :150]) < 1e-2
 
 
+def test_hear_runtime_timestamp_embeddings_vs_oracle():
+    """HEAR-2021 wrapper (reference hear_api/runtime.py): loudness normalisation, 2.01 s windows, padded-token key mask,
+    cut-off and timestamps, on the base model, against the oracle's restatement (CPU, fp32)."""
+    from hear_api.runtime import RuntimeJEPA
+    from oracle import hear_oracle as HO
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    ext = ConvFeatureExtractor(conv_layers_spec=list(J.WAVJEPA_CONV_SPEC), in_channels=1)
+    rt = RuntimeJEPA(in_channels=1, weights=None, is_spectrogram=False, process_seconds=2.01, extractor=ext, model_size="base", sr=16000)
+    shapes = {k: tuple(v.shape) for k, v in rt.model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=23).items()}
+    sd["pos_encoding_encoder"] = J.sincos_positions(768, 200)
+    sd["pos_encoding_decoder"] = J.sincos_positions(384, 200)
+    rt.model.load_state_dict(sd)
+    assert rt.scene_embedding_size == 768 and rt.timestamp_embedding_size == 768 and rt.sample_rate == 16000
+    for n_samples in (16000, 50000):
+        wave = torch.from_numpy(synth.synth_audio(2, 1, n_samples, seed=29 + n_samples)).float()[:, 0]      # [B, n]
+        emb, ts = rt.get_timestamp_embeddings(wave)
+        feats = rt.to_feature(wave).cpu()
+        ref, ref_ts = HO.timestamp_embeddings(sd, feats, mode="fp32")
+        assert emb.shape == ref.shape and ts.shape == ref_ts.shape
+        assert torch.allclose(ts.cpu(), ref_ts, atol=1e-3)
+        assert rel(emb, ref) < 2e-2, (n_samples, rel(emb, ref))
+        scene = rt.get_scene_embeddings(wave)
+        assert scene.shape == (2, 768) and rel(scene, ref.mean(1)) < 2e-2
+
+
 def test_state_dict_roundtrip_and_reference_checkpoint_layout():
     m, P = build(SMALL)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
