@@ -254,6 +254,7 @@ def main():
             # of the rows the ragged execution does not compute -- the rate a dense-shape implementation would need to keep up
             "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1),
             "final_loss": round(loss, 5),
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
