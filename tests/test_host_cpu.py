@@ -215,8 +215,57 @@ def test_conv_geometry_and_mask_plan():
     assert plan.dec_rows.tolist() == [0, 1, 2, 5, 6, 7, 8, 11, 12, 13, 15] and plan.n_dec == 11
     assert plan.dec_off.tolist() == [0, 3, 6, 8, 11] and plan.max_dec == 3
     assert plan.dec_map.tolist() == [0, 1, 2, -1, -1, 3, 4, 5, 6, -1, -1, 7, 8, 9, -1, 10]
+    # target rows among the packed predictor rows (the last predictor layer keeps only these after its attention)
+    assert plan.n_tgt == 3 and plan.tgt_rows.tolist() == [0, 5, 9] and plan.tgt_dense.tolist() == [0, 7, 13]
+    assert plan.tgt_inv.tolist() == [0, -1, -1, -1, -1, 1, -1, -1, -1, 2, -1]
     vis[0, 0, 0] = True                                            # a key-masked target: not expressible in ragged form
     assert not make_mask_plan(ctx, tgt, vis, torch.device("cpu")).ragged_ok
+
+
+def test_conv_active_rows_against_brute_force():
+    """Row lists of the sparse conv backward: every row that can carry gradient is listed, the dgrad row list is the halo-grown
+    set, and the dgrad outputs of layer l are exactly the listed rows of layer l-1 (interval arithmetic vs dense propagation)."""
+    from wavjepa_amd.engine import conv_active_rows, conv_geometry
+    L, P = conv_geometry(32159, SPEC)
+    rng = np.random.default_rng(5)
+    N = 6
+    keep = np.zeros((N, L[-1]), bool)
+    for n in range(N):
+        for st in rng.integers(0, L[-1] - 12, size=rng.integers(1, 7)):
+            keep[n, st:st + rng.integers(1, 12)] = True
+    keep[0] = False                                   # a clip without any context row
+    keep[1, :] = True                                 # ... and one that is all context
+    keep[2, -1] = True                                # the last token of a clip
+    out = conv_active_rows(keep, P, SPEC)
+    cur = np.zeros((N, P[-1]), bool)
+    cur[:, :L[-1]] = keep
+    for l in range(len(SPEC) - 1, 0, -1):
+        _, k, s = SPEC[l]
+        act, ext = out[l]
+        assert np.all(np.diff(act) > 0) and np.all(np.diff(ext) > 0)
+        assert np.isin(np.flatnonzero(cur.reshape(-1)), act).all()          # superset of the truly active rows
+        a2 = np.zeros(N * P[l], bool)
+        a2[act] = True
+        a2 = a2.reshape(N, P[l])
+        grown = a2.copy()
+        for h in range(1, -(-k // s)):
+            grown[:, h:] |= a2[:, :-h]
+        assert np.array_equal(np.flatnonzero(grown.reshape(-1)), ext)
+        written = np.zeros((N, P[l - 1]), bool)
+        e = np.flatnonzero(grown.reshape(-1))
+        for rho in range(s):
+            written[e // P[l], (e % P[l]) * s + rho] = True
+        assert np.array_equal(np.flatnonzero(written.reshape(-1)), out[l - 1][0])
+        assert int(grown[:, L[l]:].sum()) <= N * (-(-k // s) - 1)             # the halo stays inside the clip's padding rows
+        nxt = np.zeros((N, P[l - 1]), bool)
+        idx = np.nonzero(cur)
+        for kk in range(k):
+            nxt[idx[0], idx[1] * s + kk] = True
+        cur = nxt
+    act0, off0 = out[0]
+    assert off0[0] == 0 and off0[-1] == act0.size and np.all(np.diff(off0) >= 0)
+    assert np.array_equal(np.bincount(act0 // P[0], minlength=N), np.diff(off0))
+    assert off0[1] == 0                                # the clip without context has no active rows anywhere
 
 
 def test_config_loader_and_factories():
