@@ -179,7 +179,7 @@ def main():
     masker = TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10, target_prob=0.25,
                                     target_length=10, ratio_cutoff=0.1)      # configs/masker/AudioSet.yaml
     source = SyntheticAudioSource(masker, batch_size=args.clips_per_gpu // S, samples_per_audio=S, n_tokens=model.total_patches,
-                                  seed=42 + rank, n_mask_sets=8, device=device)
+                                  seed=42 + rank, n_mask_sets=64, device=device)      # masks pre-generated for 64 steps and cycled
     runner = StepRunner(model, gradient_clip_val=5.0)
 
     def sync():
