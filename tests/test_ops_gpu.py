@@ -375,6 +375,39 @@ def test_attention_ragged_matches_key_masked(ops, B, T, H, hd):
         ops.attn_fwd(pk, out_r, B=B, T=Tmax, H=H, hd=hd, seq_off=off, key_mask=mask.to(torch.uint8).contiguous())
 
 
+def test_attention_ragged_with_empty_sequence(ops):
+    """A sequence of length 0 in the packed form (no visible token) is skipped; its neighbours are unaffected."""
+    H, hd = 2, 32
+    D = H * hd
+    lens = torch.tensor([5, 0, 17, 0, 1])
+    B = int(lens.numel())
+    off = torch.zeros(B + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    n = int(off[-1])
+    pk = rnd(n, 3 * D, dtype=torch.bfloat16, seed=37)
+    out = torch.zeros(n, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(n, H, device=dev())
+    ops.attn_fwd(pk, out, B=B, T=int(lens.max()), H=H, hd=hd, seq_off=off.to(dev()), lse=lse)
+    dout = rnd(n, D, dtype=torch.bfloat16, seed=38)
+    dq = torch.zeros_like(pk)
+    dbias = torch.zeros(3 * D, device=dev())
+    ws = torch.zeros(B, 3 * D, device=dev())
+    ops.attn_bwd(pk, out, dout, lse, dq, B=B, T=int(lens.max()), H=H, hd=hd, seq_off=off.to(dev()), dbias=dbias, dbias_ws=ws)
+    x = pk.float().requires_grad_(True)
+    refs = []
+    for b in range(B):
+        lo, hi = int(off[b]), int(off[b + 1])
+        if hi > lo:
+            r, _ = ref_attention(x[lo:hi][None], H, None)
+            refs.append(r[0])
+    ref = torch.cat(refs, 0)
+    assert relerr(out.float(), ref) < 8e-3
+    ref.backward(dout.float())
+    assert relerr(dq.float(), x.grad) < 1.5e-2
+    assert relerr(dbias, dq.float().sum(0)) < 1e-4
+    assert bool(torch.isfinite(dq.float()).all()) and float(ws[1].abs().max()) == 0.0 and float(ws[3].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------------------ conv0
 @pytest.mark.parametrize("N,C_in,L,C", [(2, 1, 32159, 512), (3, 1, 4000, 32), (2, 2, 4000, 64)])
 def test_conv0_fwd_bwd(ops, N, C_in, L, C):
