@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 2
+#define WJ_ABI_VERSION 3
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -76,9 +76,12 @@ int wj_gemm_bf16(const wj_gemm_args*, void* stream);
  *   s = x (+ r);  y = (s - mean) * rstd * gamma + beta
  *   x: f32, or bf16 when x_is_bf16;  r: bf16 or NULL;  outputs y_f32 / y_bf16 / mean / rstd are each optional.
  *   Input row m is read at row (m / in_valid) * in_seg + (m % in_valid) when in_seg > 0 (padded conv token buffer).
- *   group_stats (optional, f32 [ceil(M / group_rows)][2], zeroed by the caller): += (sum y, sum y^2) of the f32 output over
- *   every group of group_rows consecutive rows -- the per-clip statistic wj_instnorm_mean needs (teacher, jepa.py:244-252).
+ *   group_stats (optional, f32 [ceil(M / group_rows)][WJ_GROUP_STATS_SPLIT][2], overwritten): partial (sum y, sum y^2) of the
+ *   f32 output over every group of group_rows consecutive rows, one pair per quarter of the group; the consumer
+ *   (wj_instnorm_mean; teacher targets, jepa.py:244-252) adds the quarters in order.  Plain stores, no float atomics:
+ *   forward activations are bit-reproducible from run to run.
  * -----------------------------------------------------------------------------------------------------------*/
+#define WJ_GROUP_STATS_SPLIT 4
 typedef struct {
     const void* x;
     const void* r;
@@ -177,7 +180,7 @@ int wj_attn_bwd(const wj_attn_bwd_args*, void* stream);
  * Replaces cnn[0] = Conv1d -> Dropout(0) -> GroupNorm(dim, dim) -> GELU (audio_feature_extractor.py:90-96).
  *   audio: bf16 [N][C_in][L];  w: bf16 [C][C_in][k];  gamma/beta: f32 [C];
  *   act: bf16 [N][P][C] (rows >= L_out of every clip are written as 0);  mean/rstd: f32 [N][C] (of the bf16-rounded
- *   conv output over time, biased variance, eps 1e-5).
+ *   conv output over time, biased variance, eps 1e-5).  C % 16 == 0 (the statistics pass runs on the matrix cores); C_in*k in {10, 20}.
  * -----------------------------------------------------------------------------------------------------------*/
 typedef struct {
     const void* audio;
@@ -187,7 +190,8 @@ typedef struct {
     void* act;
     float* mean;
     float* rstd;
-    float* workspace; /* f32 [N][C][2] scratch (sum, sum of squares) */
+    float* workspace; /* f32 scratch, wj_workspace_bytes("wj_conv0_gn_gelu_fwd") bytes: [N][C][2] folded (sum, sum of squares),
+                         then one partial record per (clip, 1024-step chunk), stored and folded in chunk order (no atomics) */
     float* yx;        /* optional f32 [N][C][C_in*k]: sum_t y_t x_{t,q}  (kept for the backward; NULL on inference)  */
     float* x1;        /* optional f32 [N][C_in*k]:    sum_t x_{t,q}      (both or neither)                            */
     int32_t N, C_in, L, C, k, stride, L_out, P;
@@ -195,11 +199,12 @@ typedef struct {
 } wj_conv0_fwd_args;
 int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args*, void* stream);
 
-/* Backward: dact bf16 [N][P][C] -> dw f32 [C][C_in][k], dgamma, dbeta (all atomically accumulated).
+/* Backward: dact bf16 [N][P][C] -> dw f32 [C][C_in][k], dgamma, dbeta (accumulated: += into the caller's gradient buffers).
  * GroupNorm spreads the gradient over the whole time axis, but that part only needs the forward's yx / x1 sums (see
  * csrc/conv0.hip); dact itself is read on the LISTED rows only: rows = int32 global row indices (n*P + t, ascending,
  * grouped by clip), row_off = int32 [N+1] offsets of every clip's rows, max_rows = the longest clip list.  rows == NULL
- * reads every row t < L_out.  workspace: f32 [N][C][2 + C_in*k]. */
+ * reads every row t < L_out.  workspace: wj_workspace_bytes("wj_conv0_gn_gelu_bwd") bytes for the same N / C / taps / L_out /
+ * max_rows (max_rows = 0 sizes for the dense form): folded [N][C][2 + C_in*k] sums + per-(clip, 256-row chunk) partials. */
 typedef struct {
     const void* audio;
     const void* w;
@@ -345,7 +350,8 @@ int wj_instnorm_accumulate(const wj_instnorm_args*, void* stream);
 
 /* The same targets in ONE pass over the K kept layer outputs (K <= 8), given their per-sample (sum, sum of squares):
  *   targets[b] = (1/K) sum_l (x_l[b] - mean_lb) * rsqrt(var_lb + eps),  mean = S1/TD, var = S2/TD - mean^2 (biased).
- * stats: f32 [K][B][2] as accumulated by wj_layernorm_fwd.group_stats.  Replaces K read-twice + read-modify-write passes. */
+ * stats: f32 [K][B][WJ_GROUP_STATS_SPLIT][2] as written by wj_layernorm_fwd.group_stats.  Replaces K read-twice +
+ * read-modify-write passes. */
 typedef struct {
     const float* x0; const float* x1; const float* x2; const float* x3;
     const float* x4; const float* x5; const float* x6; const float* x7;

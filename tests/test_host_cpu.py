@@ -29,7 +29,7 @@ def small_model(**kw):
 def test_abi_library_exports_every_declared_symbol():
     from wavjepa_amd import _abi
     lib = _abi.load()
-    assert lib.wj_abi_version() == 2
+    assert lib.wj_abi_version() == _abi.DEFINES["WJ_ABI_VERSION"] == 3
     assert len(_abi.FUNCTIONS) >= 25
     for fn in _abi.FUNCTIONS:
         assert hasattr(lib, fn), fn
@@ -186,7 +186,10 @@ def test_workspace_query():
     from wavjepa_amd import ops
     assert ops.workspace_bytes("wj_layernorm_bwd", D=768) == 1536 * 3 * 768 * 4
     assert ops.workspace_bytes("wj_attn_bwd", B=1024, H=12, hd=32) == 1024 * 3 * 384 * 4
-    assert ops.workspace_bytes("wj_conv0_gn_gelu_bwd", N=256, C=512, C_in=1, k=10) == 256 * 512 * 12 * 4
+    # conv0: folded sums + one partial record per (clip, chunk) -- stored and folded in order, no float atomics
+    assert ops.workspace_bytes("wj_conv0_gn_gelu_fwd", N=256, C=512, C_in=1, k=10, L_out=6430) == (2 * 256 * 512 + 256 * 7 * (512 * 12 + 10)) * 4
+    assert ops.workspace_bytes("wj_conv0_gn_gelu_bwd", N=256, C=512, C_in=1, k=10, L_out=6430) == 256 * (1 + 26) * 512 * 12 * 4
+    assert ops.workspace_bytes("wj_conv0_gn_gelu_bwd", N=256, C=512, C_in=1, k=10, L_out=6430, max_rows=1300) == 256 * (1 + 6) * 512 * 12 * 4
     assert ops.workspace_bytes("wj_masked_mse", B=256, G=4, T=200) == (2 + 204800) * 4
     from wavjepa_amd import _abi
     lib = _abi.load()

@@ -421,11 +421,17 @@ def test_conv0_fwd_bwd(ops, N, C_in, L, C):
     beta = 0.1 * rnd(C, seed=43)
     act = torch.empty(N, P, C, dtype=torch.bfloat16, device=dev())
     stats = torch.empty(2, N, C, device=dev())
-    ws = torch.empty(N, C, 2, device=dev())
+    dims = dict(N=N, C_in=C_in, C=C, k=k, L_out=L_out)
+    ws = torch.full((ops.workspace_bytes("wj_conv0_gn_gelu_fwd", **dims) // 4,), float("nan"), device=dev())   # scratch needs no zeroing
     yx = torch.empty(N, C, C_in * k, device=dev())
     x1 = torch.empty(N, C_in * k, device=dev())
     ops.conv0_fwd(audio, wb, gamma, beta, act, stats[0], stats[1], ws, N=N, C_in=C_in, L=L, C=C, k=k, stride=s, L_out=L_out, P=P,
                   yx=yx, x1=x1)
+    # no float atomics in the statistics: a second run reproduces every bit (activations, statistics, the sums kept for the backward)
+    act_b, stats_b, yx_b, x1_b = torch.empty_like(act), torch.empty_like(stats), torch.empty_like(yx), torch.empty_like(x1)
+    ops.conv0_fwd(audio, wb, gamma, beta, act_b, stats_b[0], stats_b[1], torch.full_like(ws, 7.0), N=N, C_in=C_in, L=L, C=C, k=k, stride=s,
+                  L_out=L_out, P=P, yx=yx_b, x1=x1_b)
+    assert torch.equal(act, act_b) and torch.equal(stats, stats_b) and torch.equal(yx, yx_b) and torch.equal(x1, x1_b)
     wr = wb.float().requires_grad_(True)
     gr = gamma.clone().requires_grad_(True)
     br = beta.clone().requires_grad_(True)
@@ -444,7 +450,7 @@ def test_conv0_fwd_bwd(ops, N, C_in, L, C):
     dw = torch.zeros(C, C_in, k, device=dev())
     dg = torch.zeros(C, device=dev())
     db = torch.zeros(C, device=dev())
-    ws2 = torch.empty(N, C, 2 + C_in * k, device=dev())
+    ws2 = torch.full((ops.workspace_bytes("wj_conv0_gn_gelu_bwd", max_rows=0, **dims) // 4,), float("nan"), device=dev())
     ops.conv0_bwd(audio, wb, gamma, beta, stats[0], stats[1], dact, dw, dg, db, ws2, yx=yx, x1=x1, N=N, C_in=C_in, L=L, C=C, k=k,
                   stride=s, L_out=L_out, P=P)
     assert relerr(dg, gr.grad) < 5e-3
@@ -480,6 +486,10 @@ def test_conv0_fwd_bwd(ops, N, C_in, L, C):
                   k=k, stride=s, L_out=L_out, P=P, rows=rows.to(dev()), row_off=off.to(dev()), max_rows=int(live.sum(1).max()))
     assert relerr(dg2, gr.grad) < 5e-3 and relerr(db2, br.grad) < 5e-3
     assert relerr(dw2, wr.grad) < 1e-2
+    dw3, dg3, db3 = torch.zeros_like(dw), torch.zeros_like(dg), torch.zeros_like(db)       # bit-reproducible as well
+    ops.conv0_bwd(audio, wb, gamma, beta, stats[0], stats[1], poison, dw3, dg3, db3, torch.full_like(ws2, 3.0), yx=yx, x1=x1, N=N, C_in=C_in,
+                  L=L, C=C, k=k, stride=s, L_out=L_out, P=P, rows=rows.to(dev()), row_off=off.to(dev()), max_rows=int(live.sum(1).max()))
+    assert torch.equal(dw2, dw3) and torch.equal(dg2, dg3) and torch.equal(db2, db3)
 
 
 def test_gelu_bwd_and_conv_weight_layouts(ops):
@@ -594,15 +604,19 @@ def test_instnorm_and_mse(ops):
     # one-pass form: the layer outputs come out of LayerNorm together with their per-sample (sum, sum of squares)
     g = 1 + 0.1 * rnd(D, seed=77)
     b = 0.1 * rnd(D, seed=78)
-    stats = torch.zeros(K, B, 2, device=dev())
+    stats = torch.full((K, B, ops.GROUP_STATS_SPLIT, 2), float("nan"), device=dev())   # written, not accumulated: no zeroing
     outs = []
     for i, x in enumerate(layers):
         y = torch.empty(B * T, D, device=dev())
         ops.layernorm_fwd(x.reshape(B * T, D), g, b, M=B * T, D=D, eps=1e-6, y_f32=y, group_stats=stats[i], group_rows=T)
         outs.append(y)
         yr = F.layer_norm(x, (D,), g, b, 1e-6)
-        assert relerr(stats[i, :, 0], yr.sum((1, 2))) < 1e-4 or maxerr(stats[i, :, 0], yr.sum((1, 2))) < 0.5
-        assert relerr(stats[i, :, 1], (yr * yr).sum((1, 2))) < 1e-5
+        got = stats[i].sum(1)
+        assert relerr(got[:, 0], yr.sum((1, 2))) < 1e-4 or maxerr(got[:, 0], yr.sum((1, 2))) < 0.5
+        assert relerr(got[:, 1], (yr * yr).sum((1, 2))) < 1e-5
+        again = torch.empty_like(stats[i])
+        ops.layernorm_fwd(x.reshape(B * T, D), g, b, M=B * T, D=D, eps=1e-6, y_f32=y, group_stats=again, group_rows=T)
+        assert torch.equal(again, stats[i])                                             # bit-reproducible
     tg2 = torch.empty(B, T, D, device=dev())
     ops.instnorm_mean(outs, stats, tg2, B=B, TD=T * D)
     ref2 = torch.stack([F.instance_norm(F.layer_norm(x, (D,), g, b, 1e-6).transpose(1, 2)[None])[0].transpose(1, 2) for x in layers]).mean(0)

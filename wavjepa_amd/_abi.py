@@ -67,7 +67,14 @@ def parse_header(path: str = HEADER) -> Tuple[Dict[str, List[Tuple[str, object]]
     return structs, funcs, enums
 
 
+def parse_defines(path: str = HEADER) -> Dict[str, int]:
+    """Integer `#define NAME value` constants of the header (WJ_ABI_VERSION, WJ_GROUP_STATS_SPLIT, ...)."""
+    text = _strip_comments(open(path).read())
+    return {k: int(v, 0) for k, v in re.findall(r"^\s*#\s*define\s+(WJ_\w+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\s*$", text, flags=re.M)}
+
+
 _STRUCT_FIELDS, FUNCTIONS, ENUMS = parse_header()
+DEFINES = parse_defines()
 
 
 def _make_struct(name: str, fields):
@@ -111,8 +118,9 @@ def load():
             f.argtypes = _NO_STREAM_FUNCS[fn]
         else:
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    if lib.wj_abi_version() != ENUMS.get("WJ_ABI_VERSION", lib.wj_abi_version()):
-        pass
+    if lib.wj_abi_version() != DEFINES["WJ_ABI_VERSION"]:
+        raise WavJepaHipError(f"{LIB_PATH} reports ABI version {lib.wj_abi_version()}, include/wavjepa_hip.h declares "
+                              f"{DEFINES['WJ_ABI_VERSION']}: stale library, rebuild it (python -m wavjepa_amd.build)")
     if not hasattr(lib, "wj_workspace_bytes"):
         raise WavJepaHipError(f"{LIB_PATH} does not export wj_workspace_bytes; rebuild it")
     lib.wj_workspace_bytes.restype = ctypes.c_int64

@@ -63,95 +63,52 @@ __device__ __forceinline__ void conv4(float (&y)[4], float (&x)[TAPS], const flo
     }
 }
 
-// ---- pass 1 (forward): per-(n,c) sum and sum of squares of the bf16-rounded conv output; when yx != NULL also
-//      YX[n][c][q] = sum_t y_t x_{t,q} and X1[n][q] = sum_t x_{t,q} (what the backward needs of the dense time axis)
+// floats per partial record of the forward statistics pass
 template <int TAPS>
-__global__ __launch_bounds__(NTH) void conv0_stats_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
-                                                          float* __restrict__ sums, float* __restrict__ yx,
-                                                          float* __restrict__ x1, Geo g, int span_max) {
-    extern __shared__ float xs[];
-    float* red = xs + g.C_in * span_max;  // [4*TAPS][128] partials of the odd-time half (yx only)
-    const int n = blockIdx.y, t0 = blockIdx.x * TC;
-    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
-    stage_audio(xs, audio, g, n, t0, span_max);
-    __syncthreads();
-    const int tmax = min(TC, g.L_out - t0);
-    for (int cb = 0; cb < g.C; cb += 512) {
-        const int c4 = cb + cl * 4;
-        const bool live = c4 < g.C;
-        float acc[4][TAPS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = 0.f;
-        if (live) {
-            float w[4][TAPS];
-            load_weights<TAPS>(w, wsrc, c4);
-            float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, xsum[TAPS];
-#pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) xsum[tp] = 0.f;
-            int off[TAPS];
-            tap_offsets<TAPS>(off, g, span_max);
-            for (int tl = half; tl < tmax; tl += 2) {
-                float y[4], x[TAPS];
-                conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[j] += y[j]; s2[j] += y[j] * y[j]; }
-                if (yx) {                                   // kernel-uniform
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int tp = 0; tp < TAPS; ++tp) acc[j][tp] = fmaf(y[j], x[tp], acc[j][tp]);
-                    if (cb == 0 && cl == 0) {
-#pragma unroll
-                        for (int tp = 0; tp < TAPS; ++tp) xsum[tp] += x[tp];
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                atomicAdd(sums + ((long)n * g.C + c4 + j) * 2 + 0, s1[j]);
-                atomicAdd(sums + ((long)n * g.C + c4 + j) * 2 + 1, s2[j]);
-            }
-            if (yx && cb == 0 && cl == 0) {
-#pragma unroll
-                for (int tp = 0; tp < TAPS; ++tp) atomicAdd(x1 + (long)n * TAPS + tp, xsum[tp]);
-            }
-        }
-        if (yx) {                                           // fold the two time-parity halves, one atomic per (c, q)
-            __syncthreads();
-            if (live && half == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tp = 0; tp < TAPS; ++tp) red[(j * TAPS + tp) * 128 + cl] = acc[j][tp];
-            }
-            __syncthreads();
-            if (live && half == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tp = 0; tp < TAPS; ++tp)
-                        atomicAdd(yx + ((long)n * g.C + c4 + j) * TAPS + tp, acc[j][tp] + red[(j * TAPS + tp) * 128 + cl]);
-            }
-        }
+__host__ __device__ constexpr long fwd_record(int C, int want_yx) { return want_yx ? 2L * C + (long)C * TAPS + TAPS : 2L * C; }
+
+// out[n][i] = sum over chunks (in chunk order) of part[n][chunk][i]; the record is split over up to three outputs
+// ([0, n0) -> o0, [n0, n0 + n1) -> o1, the rest -> o2, each [N][.]).  cnt_off != NULL: clip n only has
+// ceil((cnt_off[n+1] - cnt_off[n]) / per_chunk) chunks written (sparse backward), else `chunks`.
+__global__ __launch_bounds__(256) void conv0_fold_kernel(const float* __restrict__ part, int chunks, long rec, float* __restrict__ o0,
+                                                         long n0, float* __restrict__ o1, long n1, float* __restrict__ o2,
+                                                         const int32_t* __restrict__ cnt_off, int per_chunk) {
+    const int n = blockIdx.y;
+    int nch = chunks;
+    if (cnt_off) nch = min(chunks, (cnt_off[n + 1] - cnt_off[n] + per_chunk - 1) / per_chunk);
+    const float* src = part + (long)n * chunks * rec;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < rec; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int ch = 0; ch < nch; ++ch) s += src[ch * rec + i];
+        if (i < n0) o0[n * n0 + i] = s;
+        else if (i < n0 + n1) o1[n * n1 + (i - n0)] = s;
+        else o2[n * (rec - n0 - n1) + (i - n0 - n1)] = s;
     }
 }
 
-// ---- pass 1 on the matrix cores (C % 16 == 0): the conv is a K = taps (padded to 32) MFMA, its bf16-rounded output feeds a
-//      second MFMA with K = time that accumulates YX, so the VALU only rounds and sums.
+// ---- pass 1 (forward) on the matrix cores (C % 16 == 0): per-(n,c) sum and sum of squares of the bf16-rounded conv output;
+//      when want_yx also YX[n][c][q] = sum_t y_t x_{t,q} and X1[n][q] = sum_t x_{t,q} (what the backward needs of the dense
+//      time axis).  The conv is a K = taps (padded to 32) MFMA, its bf16-rounded output feeds a second MFMA with K = time that
+//      accumulates YX, so the VALU only rounds and sums.
+//      Every workgroup (one TCS-step chunk of one clip) STORES its partial record
+//          part[n][chunk][ 2C sums | C*TAPS yx | TAPS x1 ]
+//      and conv0_fold_kernel adds the chunks in chunk order: no float atomics, so the GroupNorm statistics -- and with them
+//      every activation of the step -- are bit-reproducible from run to run.
 //   mfma(P, Q): lane (i, g) gets  sum_k Q[row i][k] P[row 4g+r][k], r < 4;  operand lane (i, g) holds row i, k = 8g .. 8g+7.
 //   conv : P = audio patches (rows = 16 time steps), Q = weights (rows = 16 channels)  -> lane: channel i, times 4g+r
 //   YX   : Q' = that result for two 16-step blocks (row = channel i, logical k = 8g+j <-> time kappa(g,j) = j<4 ? 4g+j : 16+4g+j-4),
 //          P' = audio patches with rows = taps and the same kappa order                  -> lane: channel i, taps 4g+r
-constexpr int TCS = 1024;  // time steps per workgroup (few, long workgroups: 12 atomics per channel per workgroup)
+constexpr int TCS = 1024;  // time steps per workgroup (few, long workgroups: 7 partial records per clip at 6430 steps)
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
-                                                               float* __restrict__ sums, float* __restrict__ yx,
-                                                               float* __restrict__ x1, Geo g, int span) {
+                                                               float* __restrict__ part, int want_yx, Geo g, int span) {
     extern __shared__ __attribute__((aligned(16))) bf16_t xa[];   // [C_in][span] samples of this chunk (0 past the clip)
     constexpr int QT = (TAPS + 15) / 16;
     const int n = blockIdx.y, t0 = blockIdx.x * TCS;
+    const long rec = fwd_record<TAPS>(g.C, want_yx);
+    float* sums = part + ((long)n * gridDim.x + blockIdx.x) * rec;   // [C][2]
+    float* yx = want_yx ? sums + 2L * g.C : nullptr;                 // [C][TAPS]
+    float* x1 = want_yx ? yx + (long)g.C * TAPS : nullptr;           // [TAPS]
     for (int ci = 0; ci < g.C_in; ++ci)
         for (int i = threadIdx.x; i < span; i += 256) {
             const long src = (long)t0 * g.stride + i;
@@ -244,8 +201,8 @@ __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __r
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
             if (gq == 0) {
-                atomicAdd(sums + ((long)n * g.C + c) * 2 + 0, a);
-                atomicAdd(sums + ((long)n * g.C + c) * 2 + 1, b);
+                sums[c * 2 + 0] = a;
+                sums[c * 2 + 1] = b;
             }
             if (yx) {
 #pragma unroll
@@ -253,7 +210,7 @@ __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __r
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int q = 16 * qt + 4 * gq + r;
-                        if (q < TAPS) atomicAdd(yx + ((long)n * g.C + c) * TAPS + q, yxa[u][qt][r]);
+                        if (q < TAPS) yx[(long)c * TAPS + q] = yxa[u][qt][r];
                     }
             }
         }
@@ -262,7 +219,7 @@ __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __r
             for (int qt = 0; qt < QT; ++qt) {
                 float v = xs1[qt];
                 v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-                if (gq == 0 && okq[qt]) atomicAdd(x1 + (long)n * TAPS + 16 * qt + i, v);
+                if (gq == 0 && okq[qt]) x1[16 * qt + i] = v;
             }
         }
     }
@@ -321,7 +278,8 @@ __global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restri
 }
 
 // ---- backward, pass over the listed rows: A1 = sum dz, A2 = sum dz xh, S[q] = sum dz x_q  per (n, c) ------------------
-// ws: f32 [N][C][2 + TAPS].  rows == NULL: every row t < L_out of every clip.  Workgroup = (chunk of BR listed rows, clip).
+// Every workgroup = (chunk of BR listed rows, clip) STORES its partial part[n][chunk][C][2 + TAPS]; conv0_fold_kernel adds a
+// clip's chunks in order (no float atomics).  rows == NULL: every row t < L_out of every clip.
 constexpr int BR = 256;
 template <int TAPS>
 __global__ __launch_bounds__(NTH) void conv0_bwd_rows_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
@@ -398,11 +356,11 @@ __global__ __launch_bounds__(NTH) void conv0_bwd_rows_kernel(const bf16_t* __res
         if (live && half == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float* o = ws + ((long)n * g.C + c4 + j) * (2 + TAPS);
-                atomicAdd(o + 0, a1[j] + red[(j * (2 + TAPS) + 0) * 128 + cl]);
-                atomicAdd(o + 1, a2[j] + red[(j * (2 + TAPS) + 1) * 128 + cl]);
+                float* o = ws + (((long)n * gridDim.x + blockIdx.x) * g.C + c4 + j) * (2 + TAPS);
+                o[0] = a1[j] + red[(j * (2 + TAPS) + 0) * 128 + cl];
+                o[1] = a2[j] + red[(j * (2 + TAPS) + 1) * 128 + cl];
 #pragma unroll
-                for (int tp = 0; tp < TAPS; ++tp) atomicAdd(o + 2 + tp, acc[j][tp] + red[(j * (2 + TAPS) + 2 + tp) * 128 + cl]);
+                for (int tp = 0; tp < TAPS; ++tp) o[2 + tp] = acc[j][tp] + red[(j * (2 + TAPS) + 2 + tp) * 128 + cl];
             }
         }
     }
@@ -440,10 +398,10 @@ __global__ __launch_bounds__(256) void conv0_bwd_final_kernel(const float* __res
         float a = 0.f, b = 0.f, d = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { a += r0[i][pl]; b += r1[i][pl]; d += r2[i][pl]; }
-        atomicAdd(dw + (long)c * TAPS + tp, a);
+        dw[(long)c * TAPS + tp] += a;            // one thread owns (c, tp): a plain accumulate into the gradient buffer
         if (tp == 0) {
-            atomicAdd(dgamma + c, b);
-            atomicAdd(dbeta + c, d);
+            dgamma[c] += b;
+            dbeta[c] += d;
         }
     }
 }
@@ -456,19 +414,19 @@ inline Geo geo_of(int N, int C_in, int L, int C, int k, int stride, int L_out, i
 template <int TAPS>
 void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStream_t s) {
     const size_t lds = (size_t)a->C_in * span_max * sizeof(float);
-    const size_t lds1 = lds + (a->yx ? (size_t)128 * 4 * TAPS * sizeof(float) : 0);
-    dim3 grid1((a->L_out + TC - 1) / TC, a->N), grid2((a->P + TC - 1) / TC, a->N), block(NTH);
-    if (a->C % 16 == 0) {
-        const int span = (TCS - 1) * a->stride + a->k;
-        hipLaunchKernelGGL(conv0_stats_mfma_kernel<TAPS>, dim3((a->L_out + TCS - 1) / TCS, a->N), dim3(256),
-                           (size_t)a->C_in * span * sizeof(bf16_t), s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->workspace,
-                           a->yx, a->x1, g, span);
-    } else {
-        hipLaunchKernelGGL(conv0_stats_kernel<TAPS>, grid1, block, lds1, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
-                           a->workspace, a->yx, a->x1, g, span_max);
-    }
+    dim3 grid2((a->P + TC - 1) / TC, a->N), block(NTH);
+    const int want_yx = a->yx != nullptr;
+    const int chunks = (a->L_out + TCS - 1) / TCS;
+    const long rec = fwd_record<TAPS>(a->C, want_yx);
+    float* sums = a->workspace;                       // [N][C][2] folded statistics
+    float* part = a->workspace + 2L * a->N * a->C;    // [N][chunks][rec] partial records
+    const int span = (TCS - 1) * a->stride + a->k;
+    hipLaunchKernelGGL(conv0_stats_mfma_kernel<TAPS>, dim3(chunks, a->N), dim3(256), (size_t)a->C_in * span * sizeof(bf16_t), s,
+                       (const bf16_t*)a->audio, (const bf16_t*)a->w, part, want_yx, g, span);
+    hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
+                       sums, 2L * a->C, a->yx, (long)a->C * TAPS, a->x1, (const int32_t*)nullptr, 1);
     hipLaunchKernelGGL(conv0_apply_kernel<TAPS>, grid2, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
-                       a->gamma, a->beta, (const float*)a->workspace, (bf16_t*)a->act, a->mean, a->rstd, g, span_max, a->eps);
+                       a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean, a->rstd, g, span_max, a->eps);
 }
 
 template <int TAPS>
@@ -478,30 +436,44 @@ void launch_bwd(const wj_conv0_bwd_args* a, const Geo& g, hipStream_t s) {
     if (max_rows <= 0) return;
     static int attr = hipFuncSetAttribute((const void*)conv0_bwd_rows_kernel<TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
-    dim3 grid((max_rows + BR - 1) / BR, a->N), block(NTH);
+    const int chunks = (max_rows + BR - 1) / BR;
+    const long rec = (long)a->C * (2 + TAPS);
+    float* folded = a->workspace;                     // [N][C][2 + TAPS]
+    float* part = a->workspace + (long)a->N * rec;    // [N][chunks][C][2 + TAPS]
+    dim3 grid(chunks, a->N), block(NTH);
     hipLaunchKernelGGL(conv0_bwd_rows_kernel<TAPS>, grid, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma,
-                       a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, a->rows, a->row_off, a->workspace, g);
+                       a->beta, a->mean, a->rstd, (const bf16_t*)a->dact, a->rows, a->row_off, part, g);
+    hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
+                       folded, rec, (float*)nullptr, 0L, (float*)nullptr, a->rows ? a->row_off : (const int32_t*)nullptr, BR);
     hipLaunchKernelGGL(conv0_bwd_final_kernel<TAPS>, dim3((a->C * TAPS + 31) / 32), dim3(256), 0, s, a->gamma, a->mean, a->rstd,
-                       (const float*)a->workspace, a->yx, a->x1, a->dw, a->dgamma, a->dbeta, g);
+                       (const float*)folded, a->yx, a->x1, a->dw, a->dgamma, a->dbeta, g);
 }
 
 }  // namespace
 
+// scratch sizes (wj_workspace_bytes): folded statistics + one partial record per (clip, chunk)
+int64_t wj_conv0_fwd_ws_bytes(const wj_conv0_fwd_args* a) {
+    const int taps = a->C_in * a->k, chunks = (a->L_out + TCS - 1) / TCS;
+    const long rec = 2L * a->C + (long)a->C * taps + taps;      // sized for the training form (yx / x1 requested)
+    return (2L * a->N * a->C + (long)a->N * chunks * rec) * 4;
+}
+int64_t wj_conv0_bwd_ws_bytes(const wj_conv0_bwd_args* a) {
+    const int taps = a->C_in * a->k;
+    const int max_rows = a->max_rows > 0 ? a->max_rows : a->L_out;   // 0: sized for the dense form (every row t < L_out)
+    const int chunks = (max_rows + BR - 1) / BR;
+    return (long)a->N * (1 + chunks) * a->C * (2 + taps) * 4;
+}
+
 extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->audio || !a->w || !a->gamma || !a->beta || !a->act || !a->mean || !a->rstd || !a->workspace) return WJ_ERR_ARG;
-    if (a->N <= 0 || a->C <= 0 || (a->C & 3) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
+    if (a->N <= 0 || a->C <= 0 || (a->C & 15) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
     if ((a->L_out - 1) * a->stride + a->k > a->L) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
     const int span_max = (TC - 1) * a->stride + a->k;
     if ((a->yx == nullptr) != (a->x1 == nullptr)) return WJ_ERR_ARG;
     const int taps = a->C_in * a->k;
-    if (hipMemsetAsync(a->workspace, 0, sizeof(float) * 2L * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
-    if (a->yx) {
-        if (hipMemsetAsync(a->yx, 0, sizeof(float) * (long)a->N * a->C * taps, s) != hipSuccess) return WJ_ERR_LAUNCH;
-        if (hipMemsetAsync(a->x1, 0, sizeof(float) * (long)a->N * taps, s) != hipSuccess) return WJ_ERR_LAUNCH;
-    }
     switch (taps) {
         case 10: launch_fwd<10>(a, g, span_max, s); break;
         case 20: launch_fwd<20>(a, g, span_max, s); break;
@@ -521,7 +493,6 @@ extern "C" int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
     const int taps = a->C_in * a->k;
-    if (hipMemsetAsync(a->workspace, 0, sizeof(float) * (2L + taps) * a->N * a->C, s) != hipSuccess) return WJ_ERR_LAUNCH;
     switch (taps) {
         case 10: launch_bwd<10>(a, g, s); break;
         case 20: launch_bwd<20>(a, g, s); break;

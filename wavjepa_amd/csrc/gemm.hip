@@ -31,8 +31,6 @@
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
 
-extern "C" int wj_gemm_bf16_v1(const wj_gemm_args* a, void* stream);
-
 namespace {
 
 constexpr int BM = 256, BK = 32, NT = 512;
@@ -680,8 +678,6 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
         if (a->a_trans && a->b_trans && a->epilogue == WJ_EPI_ATOMIC_F32) return launch<true, true, WJ_EPI_ATOMIC_F32, 256, false, 2>(a, s);
         return WJ_ERR_UNSUPPORTED;
     }
-    static const bool use_v1 = getenv("WJ_GEMM_V1") != nullptr;
-    if (use_v1) return wj_gemm_bf16_v1(a, stream);
     if (!a->a_trans && !a->b_trans) return dispatch_epi<false, false>(a, s);
     if (!a->a_trans && a->b_trans) return dispatch_epi<false, true>(a, s);
     if (a->a_trans && a->b_trans) return dispatch_epi<true, true>(a, s);

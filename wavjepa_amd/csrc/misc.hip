@@ -289,7 +289,12 @@ __global__ __launch_bounds__(256) void instnorm_mean_kernel(wj_instnorm_mean_arg
     for (int l = 0; l < 8; ++l) {
         mu[l] = sc[l] = 0.f;
         if (l < a.K) {
-            const float s1 = a.stats[((long)l * a.B + b) * 2], s2 = a.stats[((long)l * a.B + b) * 2 + 1];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < WJ_GROUP_STATS_SPLIT; ++p) {       // fixed order: bit-reproducible targets
+                s1 += a.stats[(((long)l * a.B + b) * WJ_GROUP_STATS_SPLIT + p) * 2];
+                s2 += a.stats[(((long)l * a.B + b) * WJ_GROUP_STATS_SPLIT + p) * 2 + 1];
+            }
             mu[l] = s1 * invn;
             sc[l] = rsqrtf(fmaxf(s2 * invn - mu[l] * mu[l], 0.f) + a.eps) * invk;
         }
@@ -501,6 +506,9 @@ extern "C" int wj_struct_size(const char* name) {
     return -1;
 }
 
+int64_t wj_conv0_fwd_ws_bytes(const wj_conv0_fwd_args* a);   // csrc/conv0.hip
+int64_t wj_conv0_bwd_ws_bytes(const wj_conv0_bwd_args* a);
+
 extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     if (!fn || !args) return -1;
     if (!strcmp(fn, "wj_layernorm_bwd")) return 1536LL * 3 * ((const wj_ln_bwd_args*)args)->D * 4;
@@ -508,14 +516,8 @@ extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
         const wj_attn_bwd_args* a = (const wj_attn_bwd_args*)args;
         return (int64_t)a->B * 3 * a->H * a->hd * 4;
     }
-    if (!strcmp(fn, "wj_conv0_gn_gelu_fwd")) {
-        const wj_conv0_fwd_args* a = (const wj_conv0_fwd_args*)args;
-        return (int64_t)a->N * a->C * 2 * 4;
-    }
-    if (!strcmp(fn, "wj_conv0_gn_gelu_bwd")) {
-        const wj_conv0_bwd_args* a = (const wj_conv0_bwd_args*)args;
-        return (int64_t)a->N * a->C * (2 + a->C_in * a->k) * 4;
-    }
+    if (!strcmp(fn, "wj_conv0_gn_gelu_fwd")) return wj_conv0_fwd_ws_bytes((const wj_conv0_fwd_args*)args);
+    if (!strcmp(fn, "wj_conv0_gn_gelu_bwd")) return wj_conv0_bwd_ws_bytes((const wj_conv0_bwd_args*)args);
     if (!strcmp(fn, "wj_masked_mse")) {
         const wj_mse_args* a = (const wj_mse_args*)args;
         return (2 + (int64_t)a->B * a->G * a->T) * 4;

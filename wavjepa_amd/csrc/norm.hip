@@ -30,7 +30,7 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-constexpr int GS_SPLIT = 4;   // workgroups per row group when group_stats is requested
+constexpr int GS_SPLIT = WJ_GROUP_STATS_SPLIT;   // workgroups per row group when group_stats is requested
 
 template <int V, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
         }
     }
     // Row assignment.  Default: rows interleaved over the grid.  With group_stats: a workgroup owns a contiguous quarter of ONE
-    // group of rows, keeps the group's (sum y, sum y^2) in registers and issues two atomics at the end (one pair per row was a
-    // 200-way contended atomic per clip: +150 us per launch).
+    // group of rows, keeps its (sum y, sum y^2) in registers and STORES the pair at the end; the consumer adds the quarters in
+    // order (no float atomics: the teacher targets are bit-reproducible).
     int m_begin = (blockIdx.x * 4 + wave) * RPW + sr, m_end = a.M, m_step = gridDim.x * 4 * RPW;
     if (a.group_stats) {
         const int grp = blockIdx.x / GS_SPLIT, part = blockIdx.x - grp * GS_SPLIT;
@@ -118,15 +118,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
             }
         }
     }
-    if (a.group_stats) {                     // kernel-uniform: fold lanes, then waves, then two atomics per workgroup
+    if (a.group_stats) {                     // kernel-uniform: fold lanes, then waves, then one pair of stores per workgroup
         __shared__ float gred[4][2];
         gs1 = wave_sum(gs1);
         gs2 = wave_sum(gs2);
         if (lane == 0) { gred[wave][0] = gs1; gred[wave][1] = gs2; }
         __syncthreads();
         if (threadIdx.x < 2) {
-            float* gsp = a.group_stats + (long)(blockIdx.x / GS_SPLIT) * 2;
-            atomicAdd(gsp + threadIdx.x, gred[0][threadIdx.x] + gred[1][threadIdx.x] + gred[2][threadIdx.x] + gred[3][threadIdx.x]);
+            float* gsp = a.group_stats + (long)blockIdx.x * 2;         // [group][GS_SPLIT][2]
+            gsp[threadIdx.x] = gred[0][threadIdx.x] + gred[1][threadIdx.x] + gred[2][threadIdx.x] + gred[3][threadIdx.x];
         }
     }
 }
@@ -140,14 +140,12 @@ template <int V, int LPR>
 __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
     constexpr int RPW = 64 / LPR;
     constexpr int CW = LPR * 4 * V;                 // columns covered (>= D)
-    __shared__ float cacc[3][CW];
+    constexpr int nw = BWD_THREADS / 64;
+    __shared__ float cacc[nw][3][CW];               // per-wave column partials, added in wave order below
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane % LPR, sr = lane / LPR;
-    constexpr int nw = BWD_THREADS / 64;
     const int D = a.D;
     const float invD = 1.0f / (float)D;
-    for (int i = threadIdx.x; i < 3 * CW; i += BWD_THREADS) (&cacc[0][0])[i] = 0.f;
-    __syncthreads();
 
     f32x4 dg[V], db[V], dbi[V], gam[V];
 #pragma unroll
@@ -249,9 +247,9 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
             if (col < D) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    atomicAdd(&cacc[0][col + e], dg[j][e]);
-                    atomicAdd(&cacc[1][col + e], db[j][e]);
-                    if (a.dbias) atomicAdd(&cacc[2][col + e], dbi[j][e]);
+                    cacc[wave][0][col + e] = dg[j][e];
+                    cacc[wave][1][col + e] = db[j][e];
+                    cacc[wave][2][col + e] = dbi[j][e];
                 }
             }
         }
@@ -259,13 +257,16 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
     __syncthreads();
     if (a.workspace) {   // plain coalesced stores of this workgroup's partials; a second kernel folds them
         float* ws = a.workspace + (long)blockIdx.x * 3 * D;
-        for (int c = threadIdx.x; c < 3 * D; c += BWD_THREADS) ws[c] = cacc[c / D][c % D];
+        for (int c = threadIdx.x; c < 3 * D; c += BWD_THREADS) {
+            const int w = c / D, cc = c % D;
+            ws[c] = cacc[0][w][cc] + cacc[1][w][cc] + cacc[2][w][cc] + cacc[3][w][cc];
+        }
         return;
     }
     for (int c = threadIdx.x; c < D; c += BWD_THREADS) {
-        if (a.dgamma) atomicAdd(a.dgamma + c, cacc[0][c]);
-        if (a.dbeta) atomicAdd(a.dbeta + c, cacc[1][c]);
-        if (a.dbias) atomicAdd(a.dbias + c, cacc[2][c]);
+        if (a.dgamma) atomicAdd(a.dgamma + c, cacc[0][0][c] + cacc[1][0][c] + cacc[2][0][c] + cacc[3][0][c]);
+        if (a.dbeta) atomicAdd(a.dbeta + c, cacc[0][1][c] + cacc[1][1][c] + cacc[2][1][c] + cacc[3][1][c]);
+        if (a.dbias) atomicAdd(a.dbias + c, cacc[0][2][c] + cacc[1][2][c] + cacc[2][2][c] + cacc[3][2][c]);
     }
 }
 

@@ -23,6 +23,15 @@ from . import ops
 from .params import FlatParams
 
 
+def _empty(*shape, dtype, device):
+    """Arena buffers are uninitialised by design (every kernel writes what a later kernel reads).  WJ_ARENA_FILL=nan poisons
+    them instead, so that a read of never-written memory shows up as NaN in the results (tools/debug_order.py)."""
+    import os
+    if os.environ.get("WJ_ARENA_FILL", "") == "nan":
+        return torch.full(shape, float("nan"), dtype=dtype, device=device)
+    return torch.empty(*shape, dtype=dtype, device=device)
+
+
 @dataclass
 class EngineConfig:
     conv_spec: Sequence[Tuple[int, int, int]]
@@ -290,11 +299,11 @@ class JepaEngine:
         for l, (_, k, s) in enumerate(self.cfg.conv_spec):
             if l == 0:
                 continue
-            self._conv_w[f"wp{l}"] = torch.empty(C, k * C, dtype=torch.bfloat16, device=self.dev)
+            self._conv_w[f"wp{l}"] = _empty(C, k * C, dtype=torch.bfloat16, device=self.dev)
             for rho in range(s):
                 U = len(range(rho, k, s))
                 if U > 0:
-                    self._conv_w[f"wd{l}_{rho}"] = torch.empty(U * C, C, dtype=torch.bfloat16, device=self.dev)
+                    self._conv_w[f"wd{l}_{rho}"] = _empty(U * C, C, dtype=torch.bfloat16, device=self.dev)
             self._conv_w[f"dwp{l}"] = torch.zeros(C, k * C, dtype=torch.float32, device=self.dev)
 
     def prepare_weights(self, force_cast: bool = False) -> None:
@@ -326,21 +335,21 @@ class JepaEngine:
         out = []
         for _ in range(layers):
             a = _Acts()
-            a.qkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
-            a.o = torch.empty(M, D, dtype=bf, device=dev)
-            a.lse = torch.empty(B * H * self.T, dtype=f32, device=dev)
-            a.p = torch.empty(M, D, dtype=bf, device=dev)
-            a.m1 = torch.empty(M, dtype=f32, device=dev)
-            a.r1 = torch.empty(M, dtype=f32, device=dev)
-            a.x1 = torch.empty(M, D, dtype=f32, device=dev)
-            a.x1b = torch.empty(M, D, dtype=bf, device=dev)
-            a.h = torch.empty(M, 4 * D, dtype=bf, device=dev)        # holds gelu'(linear1 output), see EPI_BIAS_GELU2
-            a.g = torch.empty(M, 4 * D, dtype=bf, device=dev)
-            a.f = torch.empty(M, D, dtype=bf, device=dev)
-            a.m2 = torch.empty(M, dtype=f32, device=dev)
-            a.r2 = torch.empty(M, dtype=f32, device=dev)
-            a.x2 = torch.empty(M, D, dtype=f32, device=dev)
-            a.x2b = torch.empty(M, D, dtype=bf, device=dev)
+            a.qkv = _empty(M, 3 * D, dtype=bf, device=dev)
+            a.o = _empty(M, D, dtype=bf, device=dev)
+            a.lse = _empty(B * H * self.T, dtype=f32, device=dev)
+            a.p = _empty(M, D, dtype=bf, device=dev)
+            a.m1 = _empty(M, dtype=f32, device=dev)
+            a.r1 = _empty(M, dtype=f32, device=dev)
+            a.x1 = _empty(M, D, dtype=f32, device=dev)
+            a.x1b = _empty(M, D, dtype=bf, device=dev)
+            a.h = _empty(M, 4 * D, dtype=bf, device=dev)        # holds gelu'(linear1 output), see EPI_BIAS_GELU2
+            a.g = _empty(M, 4 * D, dtype=bf, device=dev)
+            a.f = _empty(M, D, dtype=bf, device=dev)
+            a.m2 = _empty(M, dtype=f32, device=dev)
+            a.r2 = _empty(M, dtype=f32, device=dev)
+            a.x2 = _empty(M, D, dtype=f32, device=dev)
+            a.x2b = _empty(M, D, dtype=bf, device=dev)
             out.append(a)
         return out
 
@@ -368,69 +377,71 @@ class JepaEngine:
                 if l > 0:
                     t, p = self._rows(N * self.P[l], C, bf)
                     self.dpre.append(t); self.dpre_ptr.append(p)
-        self.gn_stats = torch.empty(2, N, C, dtype=f32, device=dev)
+        self.gn_stats = _empty(2, N, C, dtype=f32, device=dev)
         taps = c.in_channels * c.conv_spec[0][1]
-        self.gn_ws = torch.empty(N, C, 2 + taps, dtype=f32, device=dev)
-        self.gn_yx = torch.empty(N, C, taps, dtype=f32, device=dev) if train else None     # forward sums the backward needs
-        self.gn_x1 = torch.empty(N, taps, dtype=f32, device=dev) if train else None
-        self.fn_b = torch.empty(M, C, dtype=bf, device=dev)
-        self.fn_mean = torch.empty(M, dtype=f32, device=dev)
-        self.fn_rstd = torch.empty(M, dtype=f32, device=dev)
-        self.map_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
-        self.lf = torch.empty(M, c.d_enc, dtype=f32, device=dev)
-        self.lf_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
+        conv0_dims = dict(N=N, C_in=c.in_channels, C=C, k=c.conv_spec[0][1], L_out=self.L[0])
+        self.gn_ws = _empty(ops.workspace_bytes("wj_conv0_gn_gelu_fwd", **conv0_dims) // 4, dtype=f32, device=dev)
+        self.gn_ws_b = _empty(ops.workspace_bytes("wj_conv0_gn_gelu_bwd", max_rows=0, **conv0_dims) // 4, dtype=f32, device=dev) if train else None
+        self.gn_yx = _empty(N, C, taps, dtype=f32, device=dev) if train else None     # forward sums the backward needs
+        self.gn_x1 = _empty(N, taps, dtype=f32, device=dev) if train else None
+        self.fn_b = _empty(M, C, dtype=bf, device=dev)
+        self.fn_mean = _empty(M, dtype=f32, device=dev)
+        self.fn_rstd = _empty(M, dtype=f32, device=dev)
+        self.map_b = _empty(M, c.d_enc, dtype=bf, device=dev)
+        self.lf = _empty(M, c.d_enc, dtype=f32, device=dev)
+        self.lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         # scratch stack (teacher / inference): one layer's worth, reused
         self.scratch = self._alloc_stack(M, c.d_enc, c.h_enc, N, 1)[0]
-        self.enc_out = torch.empty(M, c.d_enc, dtype=f32, device=dev)
-        self.enc_out_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
-        self.enc_fm = torch.empty(M, dtype=f32, device=dev)
-        self.enc_fr = torch.empty(M, dtype=f32, device=dev)
+        self.enc_out = _empty(M, c.d_enc, dtype=f32, device=dev)
+        self.enc_out_b = _empty(M, c.d_enc, dtype=bf, device=dev)
+        self.enc_fm = _empty(M, dtype=f32, device=dev)
+        self.enc_fr = _empty(M, dtype=f32, device=dev)
         if not train:
             return
         self.enc_acts = self._alloc_stack(M, c.d_enc, c.h_enc, N, c.l_enc)
         self.dec_acts = self._alloc_stack(Mp, c.d_dec, c.h_dec, N * G, c.l_dec)
-        self.ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)       # gathered context rows (<= M)
-        self.enc_in = torch.empty(M, c.d_enc, dtype=f32, device=dev)      # ragged: local features of the context rows
-        self.enc_in_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
-        self.tail_o = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)      # last predictor layer: target rows of o / x_in / do
-        self.tail_x = torch.empty(Mp, c.d_dec, dtype=f32, device=dev)
-        self.tail_do = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
-        self.cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)           # contextual_features
-        self.dec_in = torch.empty(Mp, c.d_dec, dtype=f32, device=dev)
-        self.dec_in_b = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
-        self.dec_out_b = torch.empty(Mp, c.d_dec, dtype=bf, device=dev)
-        self.dec_fm = torch.empty(Mp, dtype=f32, device=dev)
-        self.dec_fr = torch.empty(Mp, dtype=f32, device=dev)
-        self.preds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
-        self.targets = torch.empty(M, c.d_enc, dtype=f32, device=dev)
+        self.ctx_in = _empty(M, c.d_enc, dtype=bf, device=dev)       # gathered context rows (<= M)
+        self.enc_in = _empty(M, c.d_enc, dtype=f32, device=dev)      # ragged: local features of the context rows
+        self.enc_in_b = _empty(M, c.d_enc, dtype=bf, device=dev)
+        self.tail_o = _empty(Mp, c.d_dec, dtype=bf, device=dev)      # last predictor layer: target rows of o / x_in / do
+        self.tail_x = _empty(Mp, c.d_dec, dtype=f32, device=dev)
+        self.tail_do = _empty(Mp, c.d_dec, dtype=bf, device=dev)
+        self.cf = _empty(M, c.d_dec, dtype=bf, device=dev)           # contextual_features
+        self.dec_in = _empty(Mp, c.d_dec, dtype=f32, device=dev)
+        self.dec_in_b = _empty(Mp, c.d_dec, dtype=bf, device=dev)
+        self.dec_out_b = _empty(Mp, c.d_dec, dtype=bf, device=dev)
+        self.dec_fm = _empty(Mp, dtype=f32, device=dev)
+        self.dec_fr = _empty(Mp, dtype=f32, device=dev)
+        self.preds = _empty(Mp, c.d_enc, dtype=bf, device=dev)
+        self.targets = _empty(M, c.d_enc, dtype=f32, device=dev)
         # teacher: outputs of the last top_k layers (fp32) and their per-clip (sum, sum of squares)
         nkeep = c.top_k if 1 < c.top_k <= 8 else 0
-        self.tea_keep = [torch.empty(M, c.d_enc, dtype=f32, device=dev) for _ in range(nkeep)]
-        self.tea_stats = torch.zeros(max(nkeep, 1), N, 2, dtype=f32, device=dev)
+        self.tea_keep = [_empty(M, c.d_enc, dtype=f32, device=dev) for _ in range(nkeep)]
+        self.tea_stats = _empty(max(nkeep, 1), N, ops.GROUP_STATS_SPLIT, 2, dtype=f32, device=dev)   # written by layernorm_fwd
         self.loss = torch.zeros(2, dtype=f32, device=dev)
-        self.mse_ws = torch.empty(ops.workspace_bytes("wj_masked_mse", B=N, G=G, T=T) // 4, dtype=f32, device=dev)
+        self.mse_ws = _empty(ops.workspace_bytes("wj_masked_mse", B=N, G=G, T=T) // 4, dtype=f32, device=dev)
         # backward scratch, one set per stack width
         self.bw = {}
         for tag, (m, d) in dict(enc=(M, c.d_enc), dec=(Mp, c.d_dec)).items():
             # buffers read by the side-stream wgrad GEMMs exist twice (layer parity), so the main chain may run one layer ahead
             self.bw[tag] = dict(
-                dy=torch.empty(m, d, dtype=f32, device=dev), ds=torch.empty(m, d, dtype=f32, device=dev),
-                dx1=torch.empty(m, d, dtype=f32, device=dev), do=torch.empty(m, d, dtype=bf, device=dev),
-                dsb2=[torch.empty(m, d, dtype=bf, device=dev) for _ in range(2)],
-                dsb1=[torch.empty(m, d, dtype=bf, device=dev) for _ in range(2)],
-                dh=[torch.empty(m, 4 * d, dtype=bf, device=dev) for _ in range(2)],
-                dqkv=[torch.empty(m, 3 * d, dtype=bf, device=dev) for _ in range(2)],
+                dy=_empty(m, d, dtype=f32, device=dev), ds=_empty(m, d, dtype=f32, device=dev),
+                dx1=_empty(m, d, dtype=f32, device=dev), do=_empty(m, d, dtype=bf, device=dev),
+                dsb2=[_empty(m, d, dtype=bf, device=dev) for _ in range(2)],
+                dsb1=[_empty(m, d, dtype=bf, device=dev) for _ in range(2)],
+                dh=[_empty(m, 4 * d, dtype=bf, device=dev) for _ in range(2)],
+                dqkv=[_empty(m, 3 * d, dtype=bf, device=dev) for _ in range(2)],
                 done=[torch.cuda.Event() for _ in range(2)], used=[False, False])
         # scratch for two-stage parameter-gradient reductions (LayerNorm: [1536][3][D]; attention in_proj bias: [B][3D])
         red_bytes = max(ops.workspace_bytes("wj_layernorm_bwd", D=max(c.d_enc, c.d_dec, C)),
                         ops.workspace_bytes("wj_attn_bwd", B=N * G, H=c.h_dec, hd=c.d_dec // c.h_dec),
                         ops.workspace_bytes("wj_attn_bwd", B=N, H=c.h_enc, hd=c.d_enc // c.h_enc))
-        self.red_ws = torch.empty(red_bytes // 4, dtype=f32, device=dev)
-        self.dpreds = torch.empty(Mp, c.d_enc, dtype=bf, device=dev)
-        self.d_cf = torch.empty(M, c.d_dec, dtype=bf, device=dev)
-        self.d_ctx_in = torch.empty(M, c.d_enc, dtype=bf, device=dev)
-        self.d_lf_b = torch.empty(M, c.d_enc, dtype=bf, device=dev)
-        self.d_fn = torch.empty(M, C, dtype=f32, device=dev)
+        self.red_ws = _empty(red_bytes // 4, dtype=f32, device=dev)
+        self.dpreds = _empty(Mp, c.d_enc, dtype=bf, device=dev)
+        self.d_cf = _empty(M, c.d_dec, dtype=bf, device=dev)
+        self.d_ctx_in = _empty(M, c.d_enc, dtype=bf, device=dev)
+        self.d_lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
+        self.d_fn = _empty(M, C, dtype=f32, device=dev)
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
@@ -645,7 +656,7 @@ class JepaEngine:
         N, G, T, De = self.N, self.cfg.groups, self.T, self.cfg.d_enc
         if not self.ragged_step:
             return self.preds.view(N * G, T, De)
-        out = torch.empty(N * G * T, De, dtype=torch.bfloat16, device=self.dev)
+        out = _empty(N * G * T, De, dtype=torch.bfloat16, device=self.dev)
         if self.tail is not None:        # preds hold the target rows only: dense position -> packed row -> target row
             inv = torch.full((N * G * T,), -1, dtype=torch.int32, device=self.dev)
             inv[self.plan.tgt_dense.long()] = torch.arange(self.plan.n_tgt, dtype=torch.int32, device=self.dev)
@@ -659,8 +670,6 @@ class JepaEngine:
         a = self.scratch
         x, xb = self.lf, self.lf_b
         fused = 1 < c.top_k <= 8
-        if fused:
-            self.tea_stats.zero_()
         kept = 0
         for i, w in enumerate(self.tea_layers):
             keep = c.l_enc - i <= c.top_k
@@ -807,7 +816,7 @@ class JepaEngine:
         ops.conv0_bwd(self.audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
                       f.ptr32("extract_audio.cnn.0.2.bias"), self.gn_stats[0], self.gn_stats[1], self.dpost_ptr[0],
                       f.gptr("extract_audio.cnn.0.0.weight"), f.gptr("extract_audio.cnn.0.2.weight"),
-                      f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws, yx=self.gn_yx, x1=self.gn_x1, N=N, C_in=c.in_channels,
+                      f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws_b, yx=self.gn_yx, x1=self.gn_x1, N=N, C_in=c.in_channels,
                       L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
                       **(dict(rows=act_rows[0][0], row_off=act_rows[0][2], max_rows=act_rows[0][3]) if sparse else {}))
         if sparse:

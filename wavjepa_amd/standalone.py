@@ -29,8 +29,8 @@ def conv_frontend_tokens(extractor, x: torch.Tensor) -> torch.Tensor:
 
     post, post_p = rows(N * P[0])
     stats = torch.empty(2, N, C, device=dev)
-    ws = torch.empty(N, C, 2, device=dev)
     _, k0, s0 = spec[0]
+    ws = torch.empty(ops.workspace_bytes("wj_conv0_gn_gelu_fwd", N=N, C_in=C_in, C=C, k=k0, L_out=L[0]) // 4, device=dev)
     ops.conv0_fwd(audio, w0, gamma, beta, post_p, stats[0], stats[1], ws, N=N, C_in=C_in, L=n_samples, C=C, k=k0, stride=s0,
                   L_out=L[0], P=P[0])
     keep = [post]
