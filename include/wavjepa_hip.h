@@ -68,6 +68,10 @@ typedef struct {
     float alpha;
 } wj_gemm_args;
 int wj_gemm_bf16(const wj_gemm_args*, void* stream);
+/* Tuning / A-B hook (tools/gemm_bench.py, tests): force the tile/schedule variant of wj_gemm_bf16 (0..3, see csrc/gemm.hip;
+ * a variant that cannot run a shape falls back to variant 0); -1 = automatic selection.  Returns the previous setting.
+ * Same effect as the WJ_GEMM_VARIANT environment variable.  Results do not depend on the variant beyond fp32 summation order. */
+int wj_gemm_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LayerNorm (fp32 statistics), optionally fused with the post-norm residual add.

@@ -19,6 +19,9 @@ Fixtures written:
   base_forward.npz    base model (d=768/12 layers, predictor 384/12, conv 512ch) with hash-synthesised
                       weights (tests/golden/synth.py), N=2: loss, per-group grad norms, tensor slices.
   misc.npz            sin-cos tables slices/checksums, EMA decay schedule, LR schedule samples.
+  base_traj.npz       (python tests/golden/make_golden.py base_traj) 100 optimisation steps of the BASE model, N=4, through
+                      the reference's training_step / EMA / clip / AdamW / schedule, fp32 and bf16-autocast: per-step loss,
+                      grad norm, lr, EMA decay, final parameter checksums and slices (the north-star trajectory).
 """
 import os
 import sys
@@ -149,7 +152,7 @@ def gen_tiny(masks):
     return m, sd, (audio, ctx, tgt, vis)
 
 
-def run_traj(m, batches, steps, warmup, total):
+def run_traj(m, batches, steps, warmup, total, autocast_bf16=False):
     trainables = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(trainables, lr=m.hparams.lr, betas=m.hparams.adam_betas, eps=m.hparams.adam_eps,
                             weight_decay=m.hparams.adam_weight_decay)
@@ -162,7 +165,11 @@ def run_traj(m, batches, steps, warmup, total):
         opt.zero_grad()
         emas.append(m._get_ema_decay())
         lrs.append(opt.param_groups[0]["lr"])
-        out = m.training_step(b, i)          # forward + EMA (reference jepa.py:318-333)
+        if autocast_bf16:                    # Lightning's precision="bf16-mixed": autocast around the step's forward only
+            with torch.autocast("cpu", dtype=torch.bfloat16):   # (one context per step: its weight-cast cache must not outlive
+                out = m.training_step(b, i)                      # the optimiser update)
+        else:
+            out = m.training_step(b, i)      # forward + EMA (reference jepa.py:318-333)
         out["loss"].backward()
         gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)   # Lightning gradient_clip_val=5, "norm"
         opt.step()
@@ -285,6 +292,52 @@ def gen_base(masks):
     return m
 
 
+def gen_base_traj(masks, steps=100):
+    """North-star trajectory (BASELINE.json: "JEPA loss within 1e-3 of reference over 100 steps"): the BASE model, N = 4 clips
+    per step, the reference's own training_step / EMA / clip / AdamW / per-step cosine schedule (Lightning's order, as
+    run_traj), lr 4e-4 with a 10-step warm-up (the stock 100 000-step warm-up would leave lr <= 4e-7 over 100 steps and hide
+    optimiser / EMA ordering errors, SURVEY 8a note on a14) and a fast EMA (0.99 -> 0.999 over 50 steps) so the teacher
+    moves.  Recorded in fp32 and under torch.autocast("cpu", bfloat16) (train.py precision "bf16-mixed")."""
+    fx = dict(steps=steps, n=4, warmup=10, total=200, ema=np.array([0.99, 0.999, 50.0]), weight_seed=7, teacher_scale=0.97,
+              audio_seeds=np.array([200, 201, 202, 203]))
+    batches = []
+    for j in range(4):
+        a = torch.from_numpy(synth.synth_audio(4, 1, 32159, seed=200 + j))
+        sl = slice(4 * (j % 2), 4 * (j % 2) + 4)
+        batches.append((a, torch.from_numpy(masks["as_ctx"][sl]), torch.from_numpy(masks["as_tgt"][sl]), torch.from_numpy(masks["as_vis"][sl])))
+    path = os.path.join(HERE, "base_traj.npz")
+    tags = [t for t in ("fp32", "bf16") if t in os.environ.get("BASE_TRAJ_TAGS", "fp32,bf16").split(",")]
+    if os.path.exists(path) and len(tags) < 2:      # regenerate one precision, keep the other
+        old = dict(np.load(path))
+        fx.update({k: v for k, v in old.items() if "::" in k and k.split("::")[0] not in tags})
+    for tag in tags:
+        t0 = time.time()
+        torch.manual_seed(0)
+        m = build_ref(BASE_SPEC, 768, 12, 12, 384, 12, 12, top_k=8)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = synth.synth_state_dict(shapes, seed=7)
+        for k in list(sd):
+            if k.startswith("teacher_encoder.") and k.endswith("weight") and sd[k].ndim == 2:
+                sd[k] = (sd[k] * np.float32(0.97)).astype(np.float32)
+        own = m.state_dict()
+        for k, v in sd.items():
+            own[k].copy_(torch.from_numpy(v))
+        m.hparams["ema_decay"], m.hparams["ema_end_decay"], m.ema_end_step = 0.99, 0.999, 50
+        if tag == "bf16":
+            bt = [(b[0].to(torch.bfloat16),) + b[1:] for b in batches]     # on_after_batch_transfer hands bf16 audio over
+            l, g, e, lr = run_traj(m, bt, steps, 10, 200, autocast_bf16=True)
+        else:
+            l, g, e, lr = run_traj(m, batches, steps, 10, 200)
+        n, s, a = checksums(m)
+        fx.update({f"{tag}::loss": l, f"{tag}::gnorm": g, f"{tag}::ema": e, f"{tag}::lr": lr, f"{tag}::names": n, f"{tag}::sum": s,
+                   f"{tag}::abs": a, f"{tag}::seconds": time.time() - t0})
+        for k in ("encoder.layers.11.linear1.weight", "teacher_encoder.layers.11.linear1.weight", "extract_audio.cnn.2.0.weight",
+                  "decoder.layers.0.self_attn.in_proj_weight"):
+            fx[f"{tag}::final_slice::{k}"] = m.state_dict()[k].detach().float().numpy().reshape(-1)[::997].copy()
+        print(tag, "trajectory", time.time() - t0, "s; loss", l[0], "->", l[-1], flush=True)
+        np.savez_compressed(os.path.join(HERE, "base_traj.npz"), **fx)
+
+
 def gen_misc():
     fx = {}
     for d in (768, 384, 64):
@@ -330,6 +383,8 @@ if __name__ == "__main__":
         gen_misc()
     if "base" in which:
         gen_base(masks)
+    if "base_traj" in which:          # ~15 min of CPU: not part of the default list
+        gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -309,3 +309,21 @@ def test_hear_runtime_padding_arithmetic():
     assert ts.shape == (2, 100) and abs(float(ts[0, 1]) - 20.0) < 1e-6
     sd = strip_compile_prefixes({"encoder._orig_mod.layers.0.linear1.weight": 1, "mask_token": 2})
     assert set(sd) == {"encoder.layers.0.linear1.weight", "mask_token"}
+
+
+def test_mask_plan_takes_group_count_from_the_masks_and_validates_shapes():
+    """reference jepa.py:402-405: nr_targets = target_indices.shape[1]; a mismatch must raise, never index out of bounds."""
+    import pytest
+    from wavjepa_amd.engine import make_mask_plan
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    for G in (1, 3, 4):
+        ctx, tgt, vis = TimeInverseBlockMasker(G, 0.65, 10, 0.25, 10, 0.1)(batch_size=2, n_times=200, in_channels=1)
+        plan = make_mask_plan(ctx, tgt, vis, torch.device("cpu"))
+        assert (plan.N, plan.G, plan.T) == (2, G, 200) and plan.vis_u8.shape == (2 * G, 200) and plan.ragged_ok
+        assert plan.n_ctx == int((~ctx).sum()) and plan.n_dec == int((~vis).sum()) and plan.n_tgt == int(tgt.sum())
+    with pytest.raises(ValueError):
+        make_mask_plan(ctx[:1], tgt, vis, torch.device("cpu"))
+    with pytest.raises(ValueError):
+        make_mask_plan(ctx, tgt, vis[:, :2], torch.device("cpu"))
+    with pytest.raises(ValueError):
+        make_mask_plan(ctx, tgt[:, 0], vis, torch.device("cpu"))

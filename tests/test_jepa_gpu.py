@@ -205,6 +205,131 @@ def test_forward_backward_parity_two_channel_audio(golden_dir):
         assert e < 3e-2, (k, e)
 
 
+@pytest.mark.parametrize("G", [2, 6])
+def test_forward_backward_parity_other_group_counts(golden_dir, G):
+    """The number of target groups per clip comes from target_indices.shape[1] (reference jepa.py:402-405;
+    masker.target_masks_per_context is a config value), not from a constant: 2 and 6 groups against the oracle, then a
+    switch back to 4 on the same module (the arena is rebuilt)."""
+    m, P = build(SMALL)
+    ctx, tgt, vis = masks(golden_dir, 3)
+    sel = [0, 1, 2, 3, 0, 1][:G]
+    tgt_g, vis_g = tgt[:, sel].contiguous(), vis[:, sel].contiguous()
+    audio = torch.from_numpy(synth.synth_audio(3, 1, 32159, seed=21)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt_g, vis_g)
+    assert m._engine.G == G and out["preds"].shape[0] == 3 * G
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt_g.to(dev()), vis_g.to(dev()), mode="bf16", **oracle_kw(SMALL))
+    lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    num, den = {}, {}
+    for k in names:
+        g = group_of(k)
+        a, b = got[k].grad.double(), P[k].grad.double()
+        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
+    for g in num:
+        assert (num[g] / max(den[g], 1e-300)) ** 0.5 < 3e-2, (G, g)
+    out4 = m(audio, ctx, tgt, vis)
+    assert m._engine.G == 4 and out4["preds"].shape[0] == 12
+    with pytest.raises(ValueError):
+        m(audio, ctx[:2], tgt, vis)                                   # masks for another batch size
+
+
+def test_data_parallel_gradient_semantics_two_micro_batches(golden_dir):
+    """What 2 data-parallel ranks compute, on one GPU: two DIFFERENT micro-batches through the engine, their flat gradient buffers
+    averaged exactly as FlatGradAllReducer does (ReduceOp.AVG, every rank's loss normalised by its LOCAL target count), against
+    the mean of the oracle's two per-rank gradients (reference jepa.py:359-362, train.py:174-179)."""
+    m, P = build(SMALL)
+    fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    names = J.trainable_names(P)
+    flat_sum, ref_sum, counts = None, {}, []
+    for r in range(2):
+        sl = slice(3 * r, 3 * r + 3)
+        ctx, tgt, vis = (torch.from_numpy(fx[k][sl]) for k in ("as_ctx", "as_tgt", "as_vis"))
+        counts.append(int(tgt.sum()))
+        audio = torch.from_numpy(synth.synth_audio(3, 1, 32159, seed=60 + r)).to(torch.bfloat16).to(dev())
+        out = m(audio, ctx, tgt, vis)
+        out["loss"].backward()
+        g = m._flat.g32.double().clone()
+        flat_sum = g if flat_sum is None else flat_sum + g
+        Pr = {k: v.detach().clone() for k, v in P.items()}
+        for k in names:
+            Pr[k].requires_grad_(True)
+        ref = J.jepa_forward(Pr, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(SMALL))
+        ref["loss"].backward()
+        for k in names:
+            ref_sum[k] = Pr[k].grad.double() + ref_sum.get(k, 0.0)
+    assert counts[0] != counts[1]
+    avg = flat_sum / 2
+    num, den = {}, {}
+    for k in names:
+        s = m._flat.by_name[k]
+        got, want = avg[s.offset:s.offset + s.numel].view(s.shape), ref_sum[k] / 2
+        g = group_of(k)
+        num[g] = num.get(g, 0.0) + float((got - want).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(want.pow(2).sum())
+    for g in num:
+        assert (num[g] / max(den[g], 1e-300)) ** 0.5 < 3e-2, (g, (num[g] / den[g]) ** 0.5)
+
+
+def test_full_size_batch_256_clips_equals_its_slices():
+    """BASELINE config 2 at size (WavJEPA-base, 256 clips per GPU) by a test, not only by the bench: one full forward +
+    backward at N = 256 is finite, and -- the loss being sum_{targets} mean_d (p - y)^2 / count -- it equals the count-weighted
+    combination of the same step run on its four 64-clip slices, and so do the gradients (clips are independent: no batch
+    statistic couples them)."""
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    m, _ = build(BASE)
+    eng = m._ensure_engine()
+    N = 256
+    rng_state = np.random.get_state()
+    ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)(batch_size=N, n_times=200, in_channels=1)
+    np.random.set_state(rng_state)
+    audio = torch.randn(N, 1, 32159, device=dev(), generator=torch.Generator(device=dev()).manual_seed(3)).to(torch.bfloat16)
+    out = m(audio, ctx, tgt, vis)
+    out["loss"].backward()
+    loss_full, count_full = float(eng.loss[0]), float(eng.loss[1])
+    assert np.isfinite(loss_full) and count_full == float(tgt.sum())
+    g_full = m._flat.g32.double().clone()
+    assert bool(torch.isfinite(g_full).all())
+    keys = ("encoder.layers.5.linear1.weight", "decoder.layers.3.self_attn.in_proj_weight", "extract_audio.cnn.3.0.weight",
+            "extract_audio.cnn.0.0.weight", "mask_token", "encoder.layers.0.norm1.weight")
+    acc, loss_acc = torch.zeros_like(g_full), 0.0
+    for i in range(0, N, 64):
+        sl = slice(i, i + 64)
+        o = m(audio[sl], ctx[sl], tgt[sl], vis[sl])
+        o["loss"].backward()
+        w = float(eng.loss[1]) / count_full
+        loss_acc += float(eng.loss[0]) * w
+        acc += m._flat.g32.double() * w
+    assert abs(loss_acc - loss_full) < 1e-5 * abs(loss_full), (loss_acc, loss_full)
+    for k in keys:
+        s = m._flat.by_name[k]
+        a, b = acc[s.offset:s.offset + s.numel], g_full[s.offset:s.offset + s.numel]
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-3, k
+
+
+def test_bench_runs_under_torch_distributed_run_with_one_rank():
+    """The driver's N > 1 launch path (python -m torch.distributed.run ... bench.py) with a 1-rank process group: RCCL
+    init, parameter broadcast, bucketed all-reduce hooks and the replica checksum all execute on the single GPU box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16",
+           "--dense-steps", "1", "--no-cpu-baseline", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["replicas_equal"] is True and line["value"] > 0 and line["dense_ms_per_step"] > 0
+    assert line["config"]["global_batch"] == 16
+
+
 def test_mask_gather_bit_exact_and_shapes(golden_dir):
     m, P = build(SMALL)
     ctx, tgt, vis = masks(golden_dir, 3)
@@ -342,6 +467,59 @@ def test_training_trajectory_vs_oracle(golden_dir):
     sd = m.state_dict()
     for k in ("encoder.layers.1.linear1.weight", "teacher_encoder.layers.1.linear1.weight", "extract_audio.cnn.2.0.weight"):
         assert rel(sd[k], P[k]) < 2e-3, k
+
+
+def test_north_star_100_step_trajectory_vs_reference(golden_dir):
+    """BASELINE.json north star: "JEPA loss within 1e-3 of reference over 100 steps".  The BASE model (196 M parameters), N = 4 clips
+    per step, 100 optimisation steps (training_step incl. EMA -> backward -> clip 5 -> AdamW -> per-step cosine schedule, 10-step
+    warm-up to lr 4e-4, EMA 0.99 -> 0.999 over 50 steps) against the trajectory the REFERENCE itself produced for the same weights,
+    audio and masks (tests/golden/base_traj.npz, written by make_golden.py importing /root/reference): its bf16-autocast run (the
+    precision train.py uses) and its fp32 run.  Tolerances: every one of the 100 losses within 1e-3 (absolute, the north-star
+    criterion) AND within 2e-2 relative of the bf16 reference while the loss falls by 2.5 orders of magnitude; gradient norms within
+    3e-2 relative; final parameter slices within 2e-3 relative L2."""
+    fx = dict(np.load(os.path.join(golden_dir, "base_traj.npz")))
+    steps, warm, total = int(fx["steps"]), int(fx["warmup"]), int(fx["total"])
+    e0, e1, e_end = (float(v) for v in fx["ema"])
+    m, _ = build(BASE, warmup_steps=warm)
+    m.trainer.max_steps = total
+    m.hparams["ema_decay"], m.hparams["ema_end_decay"], m.ema_end_step = e0, e1, int(e_end)
+    oc = m.configure_optimizers()
+    opt, sch = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    opt.max_grad_norm = 5.0
+    mk = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+    batches = []
+    for j, seed in enumerate(fx["audio_seeds"].tolist()):
+        sl = slice(4 * (j % 2), 4 * (j % 2) + 4)
+        audio = torch.from_numpy(synth.synth_audio(4, 1, 32159, seed=int(seed))).to(torch.bfloat16).to(dev())
+        batches.append((audio,) + tuple(torch.from_numpy(mk[k][sl]) for k in ("as_ctx", "as_tgt", "as_vis")))
+    losses, gnorms = [], []
+    for i in range(steps):
+        m.global_step = i
+        out = m.training_step(batches[i % len(batches)], i)
+        out["loss"].backward()
+        opt.step()
+        sch.step()
+        losses.append(out["loss"].detach())
+        gnorms.append(opt.grad_norm().clone())
+    losses = torch.stack(losses).double().cpu().numpy()
+    gnorms = torch.stack(gnorms).double().cpu().numpy().reshape(-1)
+    for tag in ("bf16", "fp32"):
+        ref = fx[f"{tag}::loss"]
+        d = np.abs(losses - ref)
+        print(f"vs reference {tag}: max |dloss| {d.max():.3e} at step {int(d.argmax())}, max rel {np.max(d / ref):.3e} at step "
+              f"{int(np.argmax(d / ref))}; loss {losses[0]:.5f} -> {losses[-1]:.6f} (reference {ref[0]:.5f} -> {ref[-1]:.6f}); "
+              f"grad norm max rel dev {np.max(np.abs(gnorms - fx[f'{tag}::gnorm']) / fx[f'{tag}::gnorm']):.3e}")
+    ref = fx["bf16::loss"]
+    assert np.max(np.abs(losses - ref)) < 1e-3                                      # north star, all 100 steps
+    assert np.max(np.abs(losses - fx["fp32::loss"])) < 1e-3
+    assert np.max(np.abs(losses - ref) / ref) < 2e-2
+    assert np.max(np.abs(gnorms - fx["bf16::gnorm"]) / fx["bf16::gnorm"]) < 3e-2
+    sd = m.state_dict()
+    for k in ("encoder.layers.11.linear1.weight", "teacher_encoder.layers.11.linear1.weight", "extract_audio.cnn.2.0.weight",
+              "decoder.layers.0.self_attn.in_proj_weight"):
+        got = sd[k].detach().float().cpu().numpy().reshape(-1)[::997]
+        want = fx[f"bf16::final_slice::{k}"]
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-3, k
 
 
 def test_inference_representation(golden_dir):

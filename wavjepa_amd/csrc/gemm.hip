@@ -205,6 +205,7 @@ struct EpiArgs {
     long ldc;
     int seg_rows, seg_valid;
     float alpha;
+    int desync;              // eight-phase schedule: start-up stagger of the first round of workgroups (see the kernel)
     const int32_t* rowmap;   // gather forms: storage row of logical row m (GATHER 1) / of logical k (GATHER 2)
 };
 
@@ -213,16 +214,174 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- eight-phase main loop (256 x 256 x 64 tile, row-form operands, K % 128 == 0) ----------------------------------------
+// Follows the 256^2 8-phase structure of the CDNA4 guide (cdna_hip_programming.md section 5), re-derived for this kernel's
+// fragment maps:
+//   * K tile = 64 deep: LDS rows are 128 B, so every global -> LDS request is a FULL 128-B line (the 32-deep tiles of the other
+//     schedules fetch 64-B half lines, which cost the L2 -> LDS path as much as whole lines: DESIGN.md section 4).
+//   * LDS = 2 parities x [A 256 rows | B 256 rows] x 128 B = 128 KiB; 16-B chunk c of row r sits at chunk position
+//     c ^ ((r >> 1) & 7): conflict-free for the ds_read_b128 lane groups (swizzle on the per-lane SOURCE address of the LDS-DMA
+//     and again on the read).
+//   * a K tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each (16 MFMAs); every phase =
+//     [fragment reads + LDS-DMA issue] -> barrier -> [MFMA cluster] -> barrier.  Waves 4-7 run one barrier behind waves 0-3,
+//     so on every SIMD one wave's MFMA cluster overlaps its partner's reads / DMA issue.
+//   * staging is by half tiles (128 rows x 64 k = 16 KiB = 2 LDS-DMA instructions per wave): A halves of tile t+1 are issued
+//     in phases 0 / 1 of tile t, both B halves of tile t+2 in phase 3 of tile t (B fragments are read in phases 0 / 1 only and the
+//     first ones stay in registers for phase 3), so a slot is re-staged >= 2 phases after its last read; ONE counted
+//     s_waitcnt vmcnt(4) per K tile (phase 3) retires tile t+1 and leaves tile t+2's B halves in flight; tile t+1 is first read
+//     one phase after that wait (the staggered group's wait sits one barrier later, still before that read).
+template <int PAR>
+__device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const char* (&pa)[4], const char* (&pb)[4], unsigned a_lo,
+                                        unsigned b_lo, int wave, bool more1, bool more2) {
+    constexpr unsigned BUF = 65536u, BOFF = 32768u;
+    char* cur = smem + PAR * BUF;
+    char* oth = smem + (PAR ^ 1) * BUF;
+    const unsigned a_hi = a_lo ^ 64u, b_hi = b_lo ^ 64u;
+    bf16x8 af[8], b0f[4], b1f[4];
+    auto lds = [&](unsigned off) { return *reinterpret_cast<const bf16x8*>(cur + off); };
+    auto dma = [&](const char*& src, char* dst) {
+        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst, 16, 0, 0);
+        src += 128;
+    };
+    // ---- phase 0: A rows 0-63 (of the wave's 128), B cols 0-31 (of its 64)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { b0f[2 * x] = lds(b_lo + x * 2048); b0f[2 * x + 1] = lds(b_hi + x * 2048); }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { af[2 * x] = lds(a_lo + x * 2048); af[2 * x + 1] = lds(a_hi + x * 2048); }
+    if (more1) { dma(pa[0], oth + (wave * 2) * 1024); dma(pa[1], oth + (wave * 2 + 1) * 1024); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni], af[2 * mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni + 1], af[2 * mi + 1], acc[mi][ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: B cols 32-63
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { b1f[2 * x] = lds(b_lo + 4096 + x * 2048); b1f[2 * x + 1] = lds(b_hi + 4096 + x * 2048); }
+    if (more1) { dma(pa[2], oth + 16384 + (wave * 2) * 1024); dma(pa[3], oth + 16384 + (wave * 2 + 1) * 1024); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], acc[mi][2 + ni], 0, 0, 0);
+            acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[mi][2 + ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: A rows 64-127
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { af[2 * x] = lds(a_lo + 8192 + x * 2048); af[2 * x + 1] = lds(a_hi + 8192 + x * 2048); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], acc[4 + mi][2 + ni], 0, 0, 0);
+            acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[4 + mi][2 + ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: no fragment reads; B of tile t+2 into THIS parity (its B rows were last read two phases ago); the wait
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+        dma(pb[0], cur + BOFF + (wave * 2) * 1024); dma(pb[1], cur + BOFF + (wave * 2 + 1) * 1024);
+        dma(pb[2], cur + BOFF + 16384 + (wave * 2) * 1024); dma(pb[3], cur + BOFF + 16384 + (wave * 2 + 1) * 1024);
+        wait_vmcnt<4>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni], af[2 * mi], acc[4 + mi][ni], 0, 0, 0);
+            acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni + 1], af[2 * mi + 1], acc[4 + mi][ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ void eight_phase_loop(f32x4 (&acc)[8][4], char* smem, const bf16_t* __restrict__ A,
+                                                 const bf16_t* __restrict__ B, long lda, long ldb, int m0, int n0, int M, int N, int K,
+                                                 int wave, int lane) {
+    constexpr unsigned BUF = 65536u, BOFF = 32768u;
+    const int nkt = K / 64;                       // even (K % 128 == 0)
+    // per-lane LDS-DMA sources: half h (128 rows), instruction u (8 rows): row = 128 h + 16 wave + 8 u + lane / 8,
+    // LDS chunk position lane % 8 holds source chunk (lane % 8) ^ ((row >> 1) & 7)
+    const char* pa[4];
+    const char* pb[4];
+#pragma unroll
+    for (int hu = 0; hu < 4; ++hu) {
+        const int row = (hu >> 1) * 128 + wave * 16 + (hu & 1) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int ga = m0 + row, gb = n0 + row;
+        ga = ga < M ? ga : M - 1;                 // rows / columns past the edge: clamped, their outputs are never stored
+        gb = gb < N ? gb : N - 1;
+        pa[hu] = reinterpret_cast<const char*>(A + (long)ga * lda + c * 8);
+        pb[hu] = reinterpret_cast<const char*>(B + (long)gb * ldb + c * 8);
+    }
+    auto dma = [&](const char*& src, char* dst) {
+        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst, 16, 0, 0);
+        src += 128;
+    };
+    // prologue: tile 0 (parity 0), then the B halves of tile 1 (parity 1)
+#pragma unroll
+    for (int hu = 0; hu < 4; ++hu) dma(pa[hu], smem + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+#pragma unroll
+    for (int hu = 0; hu < 4; ++hu) dma(pb[hu], smem + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+    if (nkt > 1) {
+#pragma unroll
+        for (int hu = 0; hu < 4; ++hu) dma(pb[hu], smem + BUF + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+        wait_vmcnt<4>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const int i = lane & 15, g = lane >> 4, wm = wave >> 2, wn = wave & 3;
+    const unsigned sw = (unsigned)((g ^ ((i >> 1) & 7)) << 4);
+    const unsigned a_lo = (unsigned)((wm * 128 + i) * 128) + sw;
+    const unsigned b_lo = BOFF + (unsigned)((wn * 64 + i) * 128) + sw;
+    if (wm == 1) __builtin_amdgcn_s_barrier();    // waves 4-7 run one barrier behind
+    for (int t = 0; t < nkt; t += 2) {
+        ep_tile<0>(acc, smem, pa, pb, a_lo, b_lo, wave, t + 1 < nkt, t + 2 < nkt);
+        ep_tile<1>(acc, smem, pa, pb, a_lo, b_lo, wave, t + 2 < nkt, t + 3 < nkt);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();    // balance the stagger
+}
+
 // GATHER 0: dense.  1: logical row m of A (row form) and of C lives at storage row rowmap[m] (conv dgrad over the active
 // rows).  2: logical k of A and B (both col form) lives at storage row rowmap[k] (conv wgrad over the active rows;
 // the list is padded with >= 256 readable entries).
-template <bool AT, bool BT, int EPI, int BN, bool STAGGER, int GATHER = 0>
+template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
 __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                                       long lda, long ldb, int M, int N, int K, int tiles_n,
                                                                       int split_k, int k_per_split, EpiArgs e) {
     using C_ = Cfg<BN>;
-    static_assert(!STAGGER || BN == 256, "the ping-pong schedule is built for the 8-wave 256x256 tile");
-    static_assert(GATHER == 0 || !STAGGER, "gather forms use the plain schedule");
+    constexpr bool STAGGER = SCHED == 1;
+    static_assert(SCHED == 0 || BN == 256, "the ping-pong / eight-phase schedules are built for the 8-wave 256x256 tile");
+    static_assert(GATHER == 0 || SCHED == 0, "gather forms use the plain schedule");
+    static_assert(SCHED != 2 || (!AT && !BT), "eight-phase schedule: row-form operands");
     static_assert(GATHER != 1 || (!AT && EPI == WJ_EPI_BF16), "row gather: row-form A, bf16 output");
     static_assert(GATHER != 2 || (AT && BT && BN == 256), "k gather: col-form A and B, 256-wide tiles");
     constexpr int S = C_::STAGES, A_BYTES = C_::A_BYTES, STAGE_BYTES = C_::STAGE_BYTES, LPT = C_::LOADS_PER_TILE, MI = C_::MI;
@@ -286,7 +445,17 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
         }
     };
 
-    if (nkt > 0) {
+    if constexpr (SCHED == 2) {
+        // De-synchronise the chip.  With one workgroup per CU every CU would compute, then every CU would write its 128 KiB of
+        // C at the same time: the HBM write burst of a round (33 MB) is then not overlapped with anything.  The workgroups of
+        // the FIRST round start a fraction of a tile apart (4 groups of CUs), and because a CU picks up its next workgroup when
+        // the previous one leaves, the offset persists: one group's C burst runs under the other groups' MFMA loops.
+        if (e.desync > 0 && blockIdx.x < 256) {
+            const int ph = (blockIdx.x >> 3) & ((e.desync >> 8) ? 7 : 3);
+            for (int w = 0; w < ph * (e.desync & 255); ++w) __builtin_amdgcn_s_sleep(8);     // 512 clocks each
+        }
+        eight_phase_loop(acc, smem, A, B, lda, ldb, m0, n0, M, N, K, wave, lane);
+    } else if (nkt > 0) {
 #pragma unroll
         for (int p = 0; p < S - 1; ++p) {
             if (p < nkt) {
@@ -597,7 +766,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     }
 }
 
-template <bool AT, bool BT, int EPI, int BN, bool STAGGER, int GATHER = 0>
+template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
 int launch(const wj_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     int split = a->split_k < 1 ? 1 : a->split_k;
@@ -608,7 +777,12 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
     e.rowmap = a->rowmap;
-    auto kern = gemm3_kernel<AT, BT, EPI, BN, STAGGER, GATHER>;
+    {   // start-up stagger in units of 2048 clocks per group step: a quarter of a tile's main loop (~2100 clocks per 64-deep K tile)
+        static const int dq = [] { const char* v = getenv("WJ_GEMM_DESYNC"); return v ? atoi(v) : 4; }();
+        e.desync = dq;
+        if (tiles_m * tiles_n * split <= 256) e.desync = 0;      // a single round: nothing to overlap with
+    }
+    auto kern = gemm3_kernel<AT, BT, EPI, BN, SCHED, GATHER>;
     constexpr int lds = Cfg<BN>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
@@ -623,10 +797,20 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 //   0 = 256x128 tile, 2 workgroups/CU    : short K, VALU-heavy epilogues (GELU), dgrad (col-form B), N % 256 != 0
 //   1 = 256x256 tile, plain schedule     : split-K wgrad (long K loop; 850-1000 TFLOP/s)
 //   2 = 256x256 tile, ping-pong schedule : forward / conv shapes with plain epilogues and K >= 512 (+9..17 % over variant 0)
-// WJ_GEMM_VARIANT=0|1|2 forces one (A/B runs; 1 and 2 need N % 256 == 0 to avoid wasted columns but stay correct).
+//   3 = 256x256x64 tile, eight-phase     : row-form operands, K % 128 == 0 (+10..15 % over variant 2 at K = 768, +35 % at 8192^3)
+// WJ_GEMM_VARIANT=0|1|2|3 (or wj_gemm_set_variant) forces one (A/B runs; 1-3 need N % 256 == 0 to avoid wasted columns but
+// stay correct; a variant that cannot run a shape falls back to 0).
+int g_forced_variant = -2;   // -2: not initialised (WJ_GEMM_VARIANT decides), -1: automatic, >= 0: forced
+
 int pick_variant(const wj_gemm_args* a) {
-    static const int forced = [] { const char* v = getenv("WJ_GEMM_VARIANT"); return v ? atoi(v) : -1; }();
+    if (g_forced_variant == -2) { const char* v = getenv("WJ_GEMM_VARIANT"); g_forced_variant = v ? atoi(v) : -1; }
+    const int forced = g_forced_variant;
+    const bool ep_ok = !a->a_trans && !a->b_trans && a->K % 128 == 0 && a->split_k <= 1;   // eight-phase schedule (variant 3)
+    if (forced == 3) return ep_ok ? 3 : 0;
     if (forced >= 0 && forced <= 2) return forced;
+    // eight-phase (64-deep tiles, full-line fetches): every row-form shape whose N fills 256-wide tiles, and N = 384 with a long
+    // K loop (the half-empty second tile still beats the 128-wide variant there); measured with tools/gemm_check.py
+    if (ep_ok && (a->N % 256 == 0 || (a->N > 256 && a->K >= 1536))) return 3;
     if (a->N % 256 != 0) return 0;
     if (a->epilogue == WJ_EPI_ATOMIC_F32) return 1;
     if (!a->a_trans && !a->b_trans && a->K >= 512 && (a->epilogue == WJ_EPI_BF16 || a->epilogue == WJ_EPI_CONV_GELU)) return 2;
@@ -636,9 +820,12 @@ int pick_variant(const wj_gemm_args* a) {
 template <bool AT, bool BT, int EPI>
 int launch_bn(const wj_gemm_args* a, hipStream_t s) {
     switch (pick_variant(a)) {
-        case 1: return launch<AT, BT, EPI, 256, false>(a, s);
-        case 2: return launch<AT, BT, EPI, 256, true>(a, s);
-        default: return launch<AT, BT, EPI, 128, false>(a, s);
+        case 1: return launch<AT, BT, EPI, 256, 0>(a, s);
+        case 2: return launch<AT, BT, EPI, 256, 1>(a, s);
+        case 3:
+            if constexpr (!AT && !BT) return launch<AT, BT, EPI, 256, 2>(a, s);
+            else return launch<AT, BT, EPI, 128, 0>(a, s);
+        default: return launch<AT, BT, EPI, 128, 0>(a, s);
     }
 }
 
@@ -658,6 +845,12 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int wj_gemm_set_variant(int variant) {
+    const int prev = g_forced_variant;
+    g_forced_variant = variant < 0 ? -1 : variant;
+    return prev;
+}
+
 extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->A || !a->B || !a->C) return WJ_ERR_ARG;
@@ -674,8 +867,8 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (a->rowmap) {
         // gather forms (sparse conv backward), one instantiation each
         if (!a->a_trans && a->b_trans && a->epilogue == WJ_EPI_BF16 && !a->colsum && !a->bias)
-            return launch<false, true, WJ_EPI_BF16, 128, false, 1>(a, s);
-        if (a->a_trans && a->b_trans && a->epilogue == WJ_EPI_ATOMIC_F32) return launch<true, true, WJ_EPI_ATOMIC_F32, 256, false, 2>(a, s);
+            return launch<false, true, WJ_EPI_BF16, 128, 0, 1>(a, s);
+        if (a->a_trans && a->b_trans && a->epilogue == WJ_EPI_ATOMIC_F32) return launch<true, true, WJ_EPI_ATOMIC_F32, 256, 0, 2>(a, s);
         return WJ_ERR_UNSUPPORTED;
     }
     if (!a->a_trans && !a->b_trans) return dispatch_epi<false, false>(a, s);

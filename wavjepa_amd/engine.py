@@ -44,7 +44,6 @@ class EngineConfig:
     h_dec: int
     l_dec: int
     top_k: int
-    groups: int = 4
     ln_eps: float = 1e-6    # transformer layers (reference types/wavjepa_configs.py:37)
     norm_eps: float = 1e-5  # feature_norms / final norms (nn.LayerNorm default)
 
@@ -58,6 +57,9 @@ class MaskPlan:
     keep: torch.Tensor      # int32 [n_ctx] flat (b*T+t) of context rows, ascending
     inv: torch.Tensor       # int32 [N*T]  position in `keep` or -1
     n_ctx: int
+    N: int = 0              # clips, target groups per clip (= target_indices.shape[1], reference jepa.py:402-405), tokens
+    G: int = 0
+    T: int = 0
     # ragged execution (visible tokens only).  The student's non-context rows are dropped by jepa.py:399 and the
     # predictor's non-target rows carry zero loss weight (jepa.py:356); being key-masked they influence nothing else,
     # so the student runs on the n_ctx context rows and the predictor on the n_dec visible rows, packed per sequence.
@@ -86,7 +88,12 @@ def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
     ctx_np = np.ascontiguousarray(np.asarray(ctx_mask, dtype=bool))
     tgt_np = np.ascontiguousarray(np.asarray(target_indices, dtype=bool))
     vis_np = np.ascontiguousarray(np.asarray(vis_mask, dtype=bool))
-    vis_np = vis_np.reshape(-1, vis_np.shape[-1])
+    if ctx_np.ndim != 2 or tgt_np.ndim != 3 or tgt_np.shape[0] != ctx_np.shape[0] or tgt_np.shape[2] != ctx_np.shape[1]:
+        raise ValueError(f"masks: expected ctx [N, T] and target_indices [N, G, T], got {ctx_np.shape} and {tgt_np.shape}")
+    n_clips, n_groups, n_tok = tgt_np.shape
+    if vis_np.size != tgt_np.size or vis_np.shape[-1] != n_tok:
+        raise ValueError(f"masks: ctx_and_target_masks must hold N*G*T = {tgt_np.size} entries with T last, got {vis_np.shape}")
+    vis_np = vis_np.reshape(-1, n_tok)
     keep_np = np.flatnonzero(~ctx_np.reshape(-1)).astype(np.int32)
     inv_np = np.full(ctx_np.size, -1, dtype=np.int32)
     inv_np[keep_np] = np.arange(keep_np.size, dtype=np.int32)
@@ -114,7 +121,7 @@ def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
         return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device, non_blocking=True)
 
     return MaskPlan(up(ctx_np, np.uint8), up(tgt_np, np.uint8), up(vis_np, np.uint8), up(keep_np, np.int32), up(inv_np, np.int32),
-                    int(keep_np.size), enc_off=up(enc_off, np.int32), dec_rows=up(dec_rows, np.int32),
+                    int(keep_np.size), N=n_clips, G=n_groups, T=n_tok, enc_off=up(enc_off, np.int32), dec_rows=up(dec_rows, np.int32),
                     dec_off=up(dec_off, np.int32), dec_map=up(dec_map, np.int32), n_dec=int(dec_rows.size),
                     tgt_rows=up(tgt_rows, np.int32), tgt_inv=up(tgt_inv, np.int32), tgt_dense=up(tgt_dense, np.int32),
                     n_tgt=int(tgt_rows.size),
@@ -221,6 +228,7 @@ class JepaEngine:
         assert all(c == self.C for c, _, _ in cfg.conv_spec), "all conv layers must have the same width"
         assert cfg.d_enc % cfg.h_enc == 0 and cfg.d_dec % cfg.h_dec == 0
         self.N = 0
+        self.G = 0              # target groups per clip of the arena (taken from the mask plan)
         # second HIP stream: work that is off the critical path (teacher forward; all weight-gradient GEMMs of the
         # backward) runs beside the main chain and fills the tails / write bursts of its kernels (WJ_SIDE_STREAM=0: off)
         import os as _os
@@ -353,13 +361,15 @@ class JepaEngine:
             out.append(a)
         return out
 
-    def alloc(self, N: int, train: bool = True) -> None:
-        if N == self.N and (not train or getattr(self, "_train_alloc", False)):
+    def alloc(self, N: int, train: bool = True, G: int = 0) -> None:
+        """(Re)build the arena for N clips (and, for training, G target groups per clip)."""
+        G = G or self.G or 1
+        if N == self.N and (not train or (getattr(self, "_train_alloc", False) and G == self.G)):
             return
         c, bf, f32, dev = self.cfg, torch.bfloat16, torch.float32, self.dev
-        T, C, G = self.T, self.C, c.groups
+        T, C = self.T, self.C
         M, Mp = N * T, N * G * T
-        self.N, self.M, self.Mp = N, M, Mp
+        self.N, self.G, self.M, self.Mp = N, G, M, Mp
         self._train_alloc = train
         nl = len(c.conv_spec)
         # conv activations (post-GELU, and pre-GELU for layers >= 1) + their gradients
@@ -415,7 +425,7 @@ class JepaEngine:
         self.preds = _empty(Mp, c.d_enc, dtype=bf, device=dev)
         self.targets = _empty(M, c.d_enc, dtype=f32, device=dev)
         # teacher: outputs of the last top_k layers (fp32) and their per-clip (sum, sum of squares)
-        nkeep = c.top_k if 1 < c.top_k <= 8 else 0
+        nkeep = min(c.top_k, c.l_enc) if 1 < c.top_k <= 8 else 0
         self.tea_keep = [_empty(M, c.d_enc, dtype=f32, device=dev) for _ in range(nkeep)]
         self.tea_stats = _empty(max(nkeep, 1), N, ops.GROUP_STATS_SPLIT, 2, dtype=f32, device=dev)   # written by layernorm_fwd
         self.loss = torch.zeros(2, dtype=f32, device=dev)
@@ -579,10 +589,12 @@ class JepaEngine:
         """Training forward.  Results: self.loss[0], self.preds, self.targets, self.cf[:n_ctx], self.lf."""
         c, f = self.cfg, self.flat
         N = audio.shape[0]
-        self.alloc(N, train=True)
+        if plan.N != N or plan.T != self.T or plan.G < 1:
+            raise ValueError(f"mask plan is for {plan.N} clips x {plan.G} groups x {plan.T} tokens; the batch has {N} clips of {self.T} tokens")
+        self.alloc(N, train=True, G=plan.G)
         self.plan = plan
         self.audio = audio
-        M, Mp, T, G = self.M, self.Mp, self.T, c.groups
+        M, Mp, T, G = self.M, self.Mp, self.T, self.G
         De, Dd = c.d_enc, c.d_dec
         self._frontend(audio)
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
@@ -646,14 +658,14 @@ class JepaEngine:
             rows = dict(rows=plan.tgt_dense, n_rows=plan.n_tgt)          # preds hold the target rows only
         else:
             rows = dict(rows=plan.dec_rows, n_rows=plan.n_dec) if self.ragged_step else {}
-        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=self.N, G=c.groups, T=self.T, D=c.d_enc,
+        ops.masked_mse(self.preds, self.targets, plan.tgt_u8, self.loss, self.mse_ws, B=self.N, G=self.G, T=self.T, D=c.d_enc,
                        dpreds=dpreds, gscale_ptr=gscale_ptr, **rows)
 
     def dense_preds(self) -> torch.Tensor:
         """Predictions as the reference shapes them, bf16 [N*G, T, d_enc].  On a ragged step only the visible rows were
         computed (with the trimmed last layer: only the target rows); the others (zero loss weight on the reference,
         jepa.py:356) read 0."""
-        N, G, T, De = self.N, self.cfg.groups, self.T, self.cfg.d_enc
+        N, G, T, De = self.N, self.G, self.T, self.cfg.d_enc
         if not self.ragged_step:
             return self.preds.view(N * G, T, De)
         out = _empty(N * G * T, De, dtype=torch.bfloat16, device=self.dev)
@@ -681,8 +693,8 @@ class JepaEngine:
                 # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
                 # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
                 x, xb = a.x2, a.x2b
-                if keep and c.top_k > 1:
-                    ops.instnorm_accumulate(x, self.targets, B=N, TD=self.T * De, accumulate=kept > 0, scale=1.0 / c.top_k)
+                if keep and c.top_k > 1:   # mean over the layers actually kept: min(top_k, layers) (reference jepa.py:249-252)
+                    ops.instnorm_accumulate(x, self.targets, B=N, TD=self.T * De, accumulate=kept > 0, scale=1.0 / min(c.top_k, c.l_enc))
             kept += int(keep)
         if fused:
             ops.instnorm_mean(self.tea_keep[:kept], self.tea_stats, self.targets, B=N, TD=self.T * De)
@@ -705,7 +717,7 @@ class JepaEngine:
         else:
             ready = on_grads_ready
         c, f, plan = self.cfg, self.flat, self.plan
-        N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, c.groups, self.C
+        N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, self.G, self.C
         De, Dd = c.d_enc, c.d_dec
         f.g32.zero_()
         rag = self.ragged_step

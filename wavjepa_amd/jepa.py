@@ -166,6 +166,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         self._t = int(sd["step"])
+        if sd.get("lr") is not None:     # LambdaLR.load_state_dict does not write the group lr back: without this the first
+            self.param_groups[0]["lr"] = float(sd["lr"])   # resumed step would run at the constructor's lr
         self._module._ensure_engine()
         flat = self._module._flat
         flat.ensure_adam_state()
@@ -250,6 +252,7 @@ class JEPA(nn.Module):
         self._student_bf16_fresh = False
         self._teacher_bf16_fresh = False
         self._grads_ready_hook = None
+        self._adam_carry = None
         self._logged: Dict[str, Any] = {}
 
     # ------------------------------------------------------------------------------------------------ construction
@@ -277,6 +280,8 @@ class JEPA(nn.Module):
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
+        if self._flat is not None and self._flat.adam_m is not None:
+            self._adam_carry = (self._flat.adam_m, self._flat.adam_v, self._flat.n)   # optimiser moments survive .to() / .cuda()
         self._flat = None          # parameters were re-created: re-flatten lazily
         self._engine = None
         return out
@@ -296,6 +301,12 @@ class JEPA(nn.Module):
                                "(there is no CPU fallback on the product path)")
         spec = self.extract_audio.conv_layers_spec
         self._flat = FlatParams(self, self.device)
+        carry = getattr(self, "_adam_carry", None)
+        if carry is not None:
+            if carry[2] != self._flat.n:
+                raise RuntimeError("optimiser state exists for a different parameter layout; rebuild the optimiser")
+            self._flat.adam_m, self._flat.adam_v = carry[0].to(self.device), carry[1].to(self.device)
+            self._adam_carry = None
         cfg = EngineConfig(conv_spec=spec, in_channels=self.extract_audio.in_channels, n_samples=self.target_length,
                            d_enc=self.encoder_embedding_dim, h_enc=self.n_encoder_heads, l_enc=self.encoder.num_layers,
                            d_dec=self.decoder_embedding_dim, h_dec=self.n_decoder_heads, l_dec=self.decoder.num_layers,
@@ -379,7 +390,7 @@ class JEPA(nn.Module):
         plan = ctx_masks if isinstance(ctx_masks, MaskPlan) else make_mask_plan(ctx_masks, target_indices, ctx_and_target_masks, self.device)
         self._prepare_weights()
         eng.forward(audio, plan)
-        N, T, G = audio.shape[0], eng.T, eng.cfg.groups
+        N, T = audio.shape[0], eng.T
         if torch.is_grad_enabled():
             loss = _EngineLoss.apply(self._anchor, self)
         else:

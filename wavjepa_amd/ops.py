@@ -84,6 +84,11 @@ def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, 
          seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
 
 
+def gemm_set_variant(variant: int) -> int:
+    """Force the GEMM tile/schedule variant (A/B runs); -1 = automatic.  Returns the previous setting."""
+    return int(_abi.load().wj_gemm_set_variant(int(variant)))
+
+
 def pick_split_k(M: int, N: int, K: int) -> int:
     """Split-K factor for the wgrad GEMM: fill the 256 CUs (tile 256 x 256 -> 1 workgroup/CU, 256 x 128 -> 2)."""
     bn = 256 if N % 256 == 0 else 128           # mirrors pick_variant() in csrc/gemm.hip for the ATOMIC (wgrad) epilogue
