@@ -119,34 +119,23 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(n_clips: int = 4, budget_s: float = 45.0):
-    """The oracle's full train step on the host cores (SURVEY 8(d)): a port of the reference algorithm (kind='port'), N = 4
-    clips, tiny (2-layer d=128) and base (12-layer d=768) models, fp32 and the bf16-autocast flow, every available core,
-    3 warm-up + 5 timed steps each, median.  Bounded: a configuration whose steps would overrun `budget_s` in total keeps its
-    median over the steps it did (>= 1 warm-up, >= 2 timed) and says so.  `value` is the BASE fp32 rate (the reference's own
-    CPU-runnable precision for the headline model); the others are listed in `detail`."""
+def _cpu_baseline_child(threads: int, n_clips: int, configs) -> None:
+    """Child process: time the oracle's train step for each (model, mode) and print one JSON line per finished configuration
+    (the parent enforces the wall-clock bound by killing this process)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import synth
     from oracle import jepa_oracle as J
     from oracle import masking_oracle as M
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, avail)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     tiny_spec = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)]
     models = {"tiny": dict(spec=tiny_spec, d_enc=128, h_enc=4, l_enc=2, d_dec=64, h_dec=4, l_dec=2, top_k=2),
               "base": dict(spec=CONV_SPEC, d_enc=768, h_enc=12, l_enc=12, d_dec=384, h_dec=12, l_dec=12, top_k=8)}
     rng = np.random.default_rng(0)
     ctx, tgt, vis = M.time_inverse_block_masks(n_clips, 200, 1, new_rng=lambda: np.random.default_rng(rng.integers(1 << 31)))
-    g = torch.Generator().manual_seed(0)
-    audio = torch.randn(n_clips, 1, 32159, generator=g)
+    audio = torch.randn(n_clips, 1, 32159, generator=torch.Generator().manual_seed(0))
     masks = (torch.from_numpy(ctx), torch.from_numpy(tgt), torch.from_numpy(vis))
-    t_start, detail = time.perf_counter(), {}
-    plan = [("tiny", "fp32", 0.05), ("tiny", "bf16", 0.05), ("base", "fp32", 0.5), ("base", "bf16", 0.4)]   # share of the budget
-    for name, mode, share in plan:
+    for name, mode in configs:
         c = models[name]
         shapes = synth.jepa_shapes(conv_spec=c["spec"], in_channels=1, d_enc=c["d_enc"], enc_layers=c["l_enc"], d_dec=c["d_dec"],
                                    dec_layers=c["l_dec"], n_tokens=200)
@@ -155,26 +144,64 @@ def cpu_baseline(n_clips: int = 4, budget_s: float = 45.0):
         P["pos_encoding_decoder"] = J.sincos_positions(c["d_dec"], 200)
         batch = (audio if mode == "fp32" else audio.to(torch.bfloat16),) + masks
         kw = dict(mode=mode, spec=c["spec"], enc_heads=c["h_enc"], dec_heads=c["h_dec"], top_k=c["top_k"])
-        state, times, warm, t_cfg = {}, [], 0, time.perf_counter()
-        limit = budget_s * share
-        for i in range(8):
+        state, times = {}, []
+        for i in range(8):                            # 3 warm-up + 5 timed; a line after every timed step (the latest one counts)
             t0 = time.perf_counter()
             J.train_step(P, state, i, batch, **kw)
             dt = time.perf_counter() - t0
-            if i < 3 and (i == 0 or time.perf_counter() - t_cfg + 3 * dt < limit):
-                warm += 1
-                continue
-            times.append(dt)
-            if len(times) >= 2 and time.perf_counter() - t_cfg + dt > limit:
-                break
-        med = sorted(times)[len(times) // 2]
-        detail[f"{name}_{mode}"] = dict(clips_per_s=round(n_clips / med, 3), ms_per_step=round(med * 1000, 1), warmup=warm, timed=len(times))
+            if i >= 3 or dt > 4.0:                    # slow configurations count from their first step on
+                times.append(dt)
+                med = sorted(times)[len(times) // 2]
+                print(json.dumps(dict(config=f"{name}_{mode}", clips_per_s=round(n_clips / med, 3), ms_per_step=round(med * 1000, 1),
+                                      warmup=i + 1 - len(times), timed=len(times), threads=threads)), flush=True)
         del P, state
-    head = detail["base_fp32"]
-    return dict(value=head["clips_per_s"], unit="clips/s", cores=cores, kind="port", cpu=_cpu_model(),
-                sample=f"oracle train step (fwd+EMA+bwd+clip+AdamW), N={n_clips} clips of 2.01 s, {cores} threads; value = WavJEPA-base fp32, "
-                       f"median of {head['timed']} timed steps after {head['warmup']} warm-up ({head['ms_per_step']} ms/step); "
-                       f"{time.perf_counter() - t_start:.0f} s of CPU work in all",
+
+
+def cpu_baseline(n_clips: int = 4, budget_s: float = 70.0):
+    """The oracle's full train step on the host cores (SURVEY 8(d)): a port of the reference algorithm (kind='port'), N = 4
+    clips, tiny (2-layer d=128) and base (12-layer d=768) models, fp32 and the bf16-autocast flow, 3 warm-up + 5 timed steps
+    each, median -- run in a CHILD process that is killed at the wall-clock bound (`budget_s`), so a slow host cannot stall the
+    bench: first with every available core, then (for what did not finish) with 32 threads.  `value` is the best BASE fp32 rate;
+    everything measured is listed in `detail`."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    order = [("base", "fp32"), ("tiny", "fp32"), ("base", "bf16"), ("tiny", "bf16")]
+    detail, t_start = {}, time.perf_counter()
+
+    def attempt(threads, configs, limit):
+        if limit < 5 or not configs:
+            return
+        spec = json.dumps(dict(threads=threads, n_clips=n_clips, configs=configs))
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", spec], stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+        try:
+            out, _ = proc.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            out, _ = proc.communicate()
+        for ln in (out or "").splitlines():
+            if ln.startswith("{"):
+                r = json.loads(ln)
+                key = f"{r.pop('config')}@{threads}t"
+                detail[key] = r
+
+    attempt(avail, order, budget_s * 0.55)
+    missing = [c for c in order if not any(k.startswith(f"{c[0]}_{c[1]}@") and v["timed"] >= 2 for k, v in detail.items())]
+    if avail > 32:
+        attempt(32, missing or [("base", "fp32")], budget_s - (time.perf_counter() - t_start))
+    base = {k: v for k, v in detail.items() if k.startswith("base_fp32@")}
+    if not base:
+        return dict(value=None, unit="clips/s", cores=avail, kind="port", cpu=_cpu_model(), sample="no configuration finished inside the bound",
+                    detail=detail)
+    key, head = max(base.items(), key=lambda kv: kv[1]["clips_per_s"])
+    return dict(value=head["clips_per_s"], unit="clips/s", cores=head["threads"], kind="port", cpu=_cpu_model(),
+                sample=f"oracle train step (fwd+EMA+bwd+clip+AdamW), N={n_clips} clips of 2.01 s; value = WavJEPA-base fp32 on {head['threads']} of "
+                       f"{avail} host threads, median of {head['timed']} timed steps after {head['warmup']} warm-up ({head['ms_per_step']} ms/step); "
+                       f"{time.perf_counter() - t_start:.0f} s of wall clock in all (bounded at {budget_s:.0f} s)",
                 detail=detail)
 
 
@@ -339,4 +366,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-child":
+        spec = json.loads(sys.argv[2])
+        _cpu_baseline_child(spec["threads"], spec["n_clips"], [tuple(c) for c in spec["configs"]])
+    else:
+        main()

@@ -248,11 +248,10 @@ def test_data_parallel_gradient_semantics_two_micro_batches(golden_dir):
     fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
     names = J.trainable_names(P)
     flat_sum, ref_sum, counts = None, {}, []
-    for r in range(2):
-        sl = slice(3 * r, 3 * r + 3)
+    for r, sl in enumerate((slice(0, 3), slice(3, 5))):          # micro-batches of 3 and 2 clips: different target counts
         ctx, tgt, vis = (torch.from_numpy(fx[k][sl]) for k in ("as_ctx", "as_tgt", "as_vis"))
         counts.append(int(tgt.sum()))
-        audio = torch.from_numpy(synth.synth_audio(3, 1, 32159, seed=60 + r)).to(torch.bfloat16).to(dev())
+        audio = torch.from_numpy(synth.synth_audio(sl.stop - sl.start, 1, 32159, seed=60 + r)).to(torch.bfloat16).to(dev())
         out = m(audio, ctx, tgt, vis)
         out["loss"].backward()
         g = m._flat.g32.double().clone()
@@ -512,8 +511,12 @@ def test_north_star_100_step_trajectory_vs_reference(golden_dir):
     ref = fx["bf16::loss"]
     assert np.max(np.abs(losses - ref)) < 1e-3                                      # north star, all 100 steps
     assert np.max(np.abs(losses - fx["fp32::loss"])) < 1e-3
-    assert np.max(np.abs(losses - ref) / ref) < 2e-2
-    assert np.max(np.abs(gnorms - fx["bf16::gnorm"]) / fx["bf16::gnorm"]) < 3e-2
+    # yardstick: the reference's OWN two precisions differ by 3.1e-4 absolute / 3.2e-3 relative in loss over these 100 steps, and
+    # by up to 20 % in gradient norm once it has fallen below 0.01 (steps > 80): relative bounds are set a small multiple above
+    rel_ref = np.max(np.abs(fx["bf16::loss"] - fx["fp32::loss"]) / fx["fp32::loss"])
+    assert np.max(np.abs(losses - ref) / ref) < max(1e-2, 3 * rel_ref)
+    big = fx["bf16::gnorm"] > 0.05
+    assert np.max((np.abs(gnorms - fx["bf16::gnorm"]) / fx["bf16::gnorm"])[big]) < 3e-2
     sd = m.state_dict()
     for k in ("encoder.layers.11.linear1.weight", "teacher_encoder.layers.11.linear1.weight", "extract_audio.cnn.2.0.weight",
               "decoder.layers.0.self_attn.in_proj_weight"):
