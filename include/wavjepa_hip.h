@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 3
+#define WJ_ABI_VERSION 4
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -80,6 +80,9 @@ int wj_gemm_set_variant(int variant);
  *   s = x (+ r);  y = (s - mean) * rstd * gamma + beta
  *   x: f32, or bf16 when x_is_bf16;  r: bf16 or NULL;  outputs y_f32 / y_bf16 / mean / rstd are each optional.
  *   Input row m is read at row (m / in_valid) * in_seg + (m % in_valid) when in_seg > 0 (padded conv token buffer).
+ *   With in_chan = S > 1 the source buffer is CHANNEL-major (conv clip index c*N + n, N = M / (S*in_valid)) while the tokens are
+ *   clip-major with the channels of a clip back to back (token m = (n*S + c)*in_valid + t, the "B (C S)" flatten of
+ *   audio_channel_feature_extractor.py:176-178): row m is read at ((c*N + n) * in_seg + t).
  *   group_stats (optional, f32 [ceil(M / group_rows)][WJ_GROUP_STATS_SPLIT][2], overwritten): partial (sum y, sum y^2) of the
  *   f32 output over every group of group_rows consecutive rows, one pair per quarter of the group; the consumer
  *   (wj_instnorm_mean; teacher targets, jepa.py:244-252) adds the quarters in order.  Plain stores, no float atomics:
@@ -100,6 +103,7 @@ typedef struct {
     int32_t x_is_bf16;
     int32_t in_seg, in_valid;
     int32_t group_rows;
+    int32_t in_chan;
     float eps;
 } wj_ln_fwd_args;
 int wj_layernorm_fwd(const wj_ln_fwd_args*, void* stream);
@@ -127,6 +131,7 @@ typedef struct {
     int32_t x_is_bf16;
     int32_t in_seg, in_valid;
     int32_t out_seg, out_valid;
+    int32_t chan;     /* S > 1: x (in_seg) and ds_bf16 (out_seg) buffers are channel-major, see wj_ln_fwd_args.in_chan */
 } wj_ln_bwd_args;
 int wj_layernorm_bwd(const wj_ln_bwd_args*, void* stream);
 
@@ -198,6 +203,9 @@ typedef struct {
                          then one partial record per (clip, 1024-step chunk), stored and folded in chunk order (no atomics) */
     float* yx;        /* optional f32 [N][C][C_in*k]: sum_t y_t x_{t,q}  (kept for the backward; NULL on inference)  */
     float* x1;        /* optional f32 [N][C_in*k]:    sum_t x_{t,q}      (both or neither)                            */
+    int64_t audio_clip_stride; /* elements between consecutive clips of `audio`; 0 = C_in*L (packed).  One channel c of an
+                         [N][C_audio][L] batch as a mono conv (ConvChannelFeatureExtractor, audio_channel_feature_extractor.py:
+                         163-172): audio = base + c*L, C_in = 1, audio_clip_stride = C_audio*L. */
     int32_t N, C_in, L, C, k, stride, L_out, P;
     float eps;
 } wj_conv0_fwd_args;
@@ -225,6 +233,7 @@ typedef struct {
     float* dgamma;
     float* dbeta;
     float* workspace;
+    int64_t audio_clip_stride; /* as in wj_conv0_fwd_args */
     int32_t N, C_in, L, C, k, stride, L_out, P;
     int32_t max_rows;
 } wj_conv0_bwd_args;

@@ -81,25 +81,60 @@ def sincos_positions(dim: int, n_pos: int) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # conv front-end
 # --------------------------------------------------------------------------------------
-def conv_frontend(P: Params, audio: torch.Tensor, spec: ConvSpec, mode: str,
-                  prefix: str = "extract_audio.") -> torch.Tensor:
-    """audio [N, C_in, L] -> tokens [N, T, C_out].
+def _conv_stack(P: Params, x: torch.Tensor, spec: ConvSpec, mode: str, stack: str) -> torch.Tensor:
+    """One stacked-Conv1d encoder with parameters `{stack}{l}.0.weight`, `{stack}0.2.{weight,bias}`: [N, C_in, L] -> [N, T, C_out].
 
     Layer l: Conv1d(no bias) -> [GroupNorm(C, C) on layer 0 only] -> erf-GELU.
     bf16 mode: conv in/out bf16; GroupNorm computed/returned fp32; GELU keeps its input dtype.
     """
-    x = audio
     for i, (dim, k, s) in enumerate(spec):
-        w = P[f"{prefix}cnn.{i}.0.weight"]
+        w = P[f"{stack}{i}.0.weight"]
         if mode == "bf16":
             x = F.conv1d(x.to(torch.bfloat16), w.to(torch.bfloat16), stride=s)
         else:
             x = F.conv1d(x.float(), w.float(), stride=s)
         if i == 0:
-            g, b = P[f"{prefix}cnn.0.2.weight"], P[f"{prefix}cnn.0.2.bias"]
+            g, b = P[f"{stack}0.2.weight"], P[f"{stack}0.2.bias"]
             x = F.group_norm(x.float(), dim, g.float(), b.float(), 1e-5)
         x = F.gelu(x)
     return x.transpose(1, 2)
+
+
+def conv_frontend(P: Params, audio: torch.Tensor, spec: ConvSpec, mode: str,
+                  prefix: str = "extract_audio.") -> torch.Tensor:
+    """audio [N, C_in, L] -> tokens.
+
+    ConvFeatureExtractor (parameters `cnn.*`; reference extractors/audio_feature_extractor.py:124-138): one stack over all
+    input channels -> [N, T, C_out].
+    ConvChannelFeatureExtractor (parameters `cnns.{c}.*`; reference extractors/audio_channel_feature_extractor.py:154-179): every
+    channel x[:, [c]] through its own MONO stack (or the single shared one), stacked and flattened channel-major
+    "B (C S)" -> [N, C_in * T, C_out].
+    """
+    if f"{prefix}cnns.0.0.0.weight" in P:
+        n_stacks = 1
+        while f"{prefix}cnns.{n_stacks}.0.0.weight" in P:
+            n_stacks += 1
+        outs = [_conv_stack(P, audio[:, c:c + 1], spec, mode, f"{prefix}cnns.{min(c, n_stacks - 1)}.") for c in range(audio.shape[1])]
+        return torch.stack(outs, dim=1).flatten(1, 2)
+    return _conv_stack(P, audio, spec, mode, f"{prefix}cnn.")
+
+
+def binaural_positions(dim: int, time_steps: int) -> torch.Tensor:
+    """reference pos_embed.py:122-151 get_binaural_pos_embed: [2 * time_steps, dim] float64 table; first half of the features =
+    sin-cos of the time step (dim / 2 wide), second half = 0 for the left channel and the sin-cos code of position 0
+    (zeros then ones) for the right channel; left rows first."""
+    assert dim % 2 == 0
+    half = dim // 2
+
+    def sincos(d, n):
+        omega = 1.0 / (10000.0 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0)))
+        ang = np.arange(n, dtype=np.float64)[:, None] * omega[None, :]
+        return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+
+    time_embed = sincos(half, time_steps)
+    left = np.concatenate([time_embed, np.zeros((time_steps, half))], axis=1)
+    right = np.concatenate([time_embed, np.tile(sincos(half, 1), (time_steps, 1))], axis=1)
+    return torch.from_numpy(np.concatenate([left, right], axis=0))
 
 
 def local_features(P: Params, audio: torch.Tensor, spec: ConvSpec, mode: str) -> torch.Tensor:

@@ -19,6 +19,8 @@ Fixtures written:
   base_forward.npz    base model (d=768/12 layers, predictor 384/12, conv 512ch) with hash-synthesised
                       weights (tests/golden/synth.py), N=2: loss, per-group grad norms, tensor slices.
   misc.npz            sin-cos tables slices/checksums, EMA decay schedule, LR schedule samples.
+  channel_frontend.npz  ConvChannelFeatureExtractor (own / shared stacks) weights + input + output, get_binaural_pos_embed
+                      slices, channel-based masks under a pinned numpy Generator sequence.
   base_traj.npz       (python tests/golden/make_golden.py base_traj) 100 optimisation steps of the BASE model, N=4, through
                       the reference's training_step / EMA / clip / AdamW / schedule, fp32 and bf16-autocast: per-step loss,
                       grad norm, lr, EMA decay, final parameter checksums and slices (the north-star trajectory).
@@ -338,6 +340,43 @@ def gen_base_traj(masks, steps=100):
         np.savez_compressed(os.path.join(HERE, "base_traj.npz"), **fx)
 
 
+def gen_channel(masks):
+    """WavJEPA-Nat front-end pieces (BASELINE config 4): the reference's ConvChannelFeatureExtractor (per-channel and shared
+    stacks) on a 2-channel input, get_binaural_pos_embed, and the channel-based masks of TimeInverseBlockMasker."""
+    from wavjepa.extractors.audio_channel_feature_extractor import ConvChannelFeatureExtractor
+    spec = [(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)]
+    fx = {}
+    torch.manual_seed(2024)
+    x = torch.randn(2, 2, 8000)
+    fx["audio"] = x.numpy()
+    for tag, share in (("own", False), ("shared", True)):
+        ext = ConvChannelFeatureExtractor(conv_layers_spec=spec, in_channels=2, share_weights_over_channels=share)
+        with torch.no_grad():
+            for n, p in ext.named_parameters():
+                if n.endswith("2.weight"):
+                    p.add_(0.1 * torch.randn_like(p))
+                elif n.endswith("2.bias"):
+                    p.add_(0.05 * torch.randn_like(p))
+            y = ext(x)
+        fx.update({f"{tag}::sd::{k}": v.detach().numpy().copy() for k, v in ext.state_dict().items()})
+        fx[f"{tag}::out"] = y.numpy()
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            fx[f"{tag}::total_patches"] = ext.total_patches(8000)
+    for d, t in ((768, 200), (64, 7)):
+        tab = R.pos_embed.get_binaural_pos_embed(d, t)
+        fx[f"binaural{d}_{t}_shape"] = np.array(tab.shape)
+        fx[f"binaural{d}_{t}_slice"] = tab[::max(1, t // 5), ::max(1, d // 16)].copy()
+        fx[f"binaural{d}_{t}_sum"] = float(tab.sum())
+        fx[f"binaural{d}_{t}_row_last"] = tab[-1].copy()
+    with PinnedRng(3000):
+        mk = R.masking.TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10,
+                                              target_prob=0.25, target_length=10, ratio_cutoff=0.1, channel_based_masking=True)
+        c, t, v = mk(batch_size=3, n_times=400, in_channels=2)
+    fx.update(cb_ctx=c.numpy(), cb_tgt=t.numpy(), cb_vis=v.numpy(), cb_base=3000)
+    np.savez_compressed(os.path.join(HERE, "channel_frontend.npz"), **fx)
+
+
 def gen_misc():
     fx = {}
     for d in (768, 384, 64):
@@ -371,7 +410,7 @@ def gen_misc():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -383,6 +422,8 @@ if __name__ == "__main__":
         gen_misc()
     if "base" in which:
         gen_base(masks)
+    if "channel" in which:
+        gen_channel(masks)
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

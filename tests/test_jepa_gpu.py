@@ -27,11 +27,15 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build(cfg, seed=7, teacher_scale=0.97, seconds=2.01, tokens=200, in_channels=1, **kw):
-    from wavjepa_amd.extractors import ConvFeatureExtractor
+def build(cfg, seed=7, teacher_scale=0.97, seconds=2.01, tokens=200, in_channels=1, channel_stacks=None, **kw):
+    from wavjepa_amd.extractors import ConvChannelFeatureExtractor, ConvFeatureExtractor
     from wavjepa_amd.jepa import JEPA
     from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
-    ext = ConvFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=in_channels)
+    if channel_stacks is None:
+        ext = ConvFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=in_channels)
+    else:   # "own" / "shared": every channel through a mono stack (WavJEPA-Nat, BASELINE config 4)
+        ext = ConvChannelFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=in_channels,
+                                          share_weights_over_channels=channel_stacks == "shared")
     m = JEPA(feature_extractor=ext,
              transformer_encoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_enc"]),
              transformer_encoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_enc"], nhead=cfg["h_enc"]),
@@ -327,6 +331,54 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["replicas_equal"] is True and line["value"] > 0 and line["dense_ms_per_step"] > 0
     assert line["config"]["global_batch"] == 16
+
+
+@pytest.mark.parametrize("stacks,ragged", [("own", True), ("shared", True), ("own", False)])
+def test_forward_backward_parity_channel_extractor(stacks, ragged):
+    """ConvChannelFeatureExtractor (reference extractors/audio_channel_feature_extractor.py:154-179; WavJEPA-Nat, BASELINE config
+    4): a 2-channel clip -> every channel through its own (or the shared) mono conv stack -> 2 x 99 tokens flattened channel-major,
+    with channel-based masks in the extractor's token order.  Loss, local features and every gradient (each channel's stack
+    separately) against the oracle; sparse and dense conv backward."""
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    m, P = build(SMALL, seconds=1.0, tokens=198, in_channels=2, channel_stacks=stacks)
+    assert m.total_patches == 198 and m.extract_audio.frames_per_channel(16000) == 99
+    m._ensure_engine().ragged = ragged
+    st = np.random.get_state()
+    ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True, channel_major=True)(
+        batch_size=3, n_times=198, in_channels=2)
+    np.random.set_state(st)
+    assert ctx.shape == (3, 198) and torch.equal(ctx[:, :99], ctx[:, 99:])
+    audio = torch.from_numpy(synth.synth_audio(3, 2, 16000, seed=31)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt, vis)
+    assert m._engine.ragged_step == ragged and m._engine.S == 2 and len(m._engine.stacks) == (2 if stacks == "own" else 1)
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(SMALL))
+    lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
+    assert rel(out["local_features"].float(), ref["local_features"].float()) < 1e-2
+    assert rel(out["targets"].float(), ref["targets"].float()) < 1e-2
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    num, den = {}, {}
+    for k in names:
+        g = ".".join(k.split(".")[:3]) if k.startswith("extract_audio.cnns") else group_of(k)     # each stack on its own
+        a, b = got[k].grad.double(), P[k].grad.double()
+        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
+    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    print(stacks, "ragged" if ragged else "dense", "loss", lo, lr_, "grad rel errors per group:", errs)
+    assert sum(1 for g in errs if g.startswith("extract_audio.cnns")) == (2 if stacks == "own" else 1)
+    for g, e in errs.items():
+        assert e < 3e-2, (g, e)
+    # the stand-alone extractor forward gives the same tokens as the oracle's front-end
+    tok = m.extract_audio(audio)
+    want = J.conv_frontend({k: v.detach() for k, v in P.items()}, audio, SMALL_SPEC, "bf16")
+    # raw conv tokens (before feature_norms): six bf16 layers deep, two independent bf16 pipelines -> 2e-2 (the normalised
+    # local_features above meet 1e-2)
+    assert tok.shape == want.shape == (3, 198, 64) and rel(tok.float(), want.float()) < 2e-2
 
 
 def test_mask_gather_bit_exact_and_shapes(golden_dir):

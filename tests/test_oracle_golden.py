@@ -209,3 +209,60 @@ def test_base_forward_backward(golden_dir):
         assert abs(tot - want[g]) < 1e-3 * want[g], (g, tot, want[g])
     assert rel(P["extract_audio.cnn.0.0.weight"].grad, fx["grad::extract_audio.cnn.0.0.weight"]) < 1e-3
     assert rel(P["encoder.layers.0.linear1.weight"].grad[::128, ::64], fx["grad_slice::encoder.layers.0.linear1.weight"]) < 1e-3
+
+
+def test_channel_frontend_binaural_positions_and_channel_masks(golden_dir):
+    """WavJEPA-Nat front-end pieces against the reference's outputs (tests/golden/channel_frontend.npz): the oracle's
+    ConvChannelFeatureExtractor restatement (own and shared stacks, channel-major flatten), get_binaural_pos_embed (oracle AND the
+    product's numpy restatement, bit-exact: float64 table), and the channel-based masks (bit-exact under the pinned generator
+    sequence; product masker = reference order by default, channel-major on request)."""
+    from oracle import masking_oracle as M
+    from wavjepa_amd.extractors import ConvChannelFeatureExtractor
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    from wavjepa_amd.pos_embed import get_binaural_pos_embed
+    fx = dict(np.load(os.path.join(golden_dir, "channel_frontend.npz")))
+    spec = [(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)]
+    audio = torch.from_numpy(fx["audio"])
+    for tag, share in (("own", False), ("shared", True)):
+        P = {"extract_audio." + k.split("::", 2)[2]: torch.from_numpy(v) for k, v in fx.items() if k.startswith(f"{tag}::sd::")}
+        out = J.conv_frontend(P, audio, spec, "fp32")
+        ref = torch.from_numpy(fx[f"{tag}::out"])
+        assert out.shape == ref.shape == (2, 2 * 49, 32)
+        assert float((out - ref).norm() / ref.norm()) < 2e-6
+        ext = ConvChannelFeatureExtractor(conv_layers_spec=spec, in_channels=2, share_weights_over_channels=share)
+        assert {k: tuple(v.shape) for k, v in ext.state_dict().items()} == {k[len("extract_audio."):]: tuple(v.shape) for k, v in P.items()}
+        assert ext.total_patches(8000) == int(fx[f"{tag}::total_patches"]) == 98 and ext.embedding_dim == 32
+    for d, t in ((768, 200), (64, 7)):
+        for tab in (J.binaural_positions(d, t).numpy(), get_binaural_pos_embed(d, t)):
+            assert tuple(tab.shape) == tuple(fx[f"binaural{d}_{t}_shape"])
+            assert np.array_equal(tab[::max(1, t // 5), ::max(1, d // 16)], fx[f"binaural{d}_{t}_slice"])
+            assert np.array_equal(tab[-1], fx[f"binaural{d}_{t}_row_last"]) and tab.sum() == float(fx[f"binaural{d}_{t}_sum"])
+    base = int(fx["cb_base"])
+
+    class Pinned:                       # k-th default_rng() call -> default_rng(base + k), as in make_golden.PinnedRng
+        def __init__(self):
+            self.k, self.orig = 0, np.random.default_rng
+
+        def __call__(self, seed=None):
+            g = self.orig(base + self.k)
+            self.k += 1
+            return g
+
+    pin = Pinned()
+    np.random.default_rng = pin
+    try:
+        c, t, v = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True)(batch_size=3, n_times=400, in_channels=2)
+    finally:
+        np.random.default_rng = pin.orig
+    assert np.array_equal(c.numpy(), fx["cb_ctx"]) and np.array_equal(t.numpy(), fx["cb_tgt"]) and np.array_equal(v.numpy(), fx["cb_vis"])
+    pin = Pinned()
+    np.random.default_rng = pin
+    try:
+        c2, t2, v2 = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True, channel_major=True)(
+            batch_size=3, n_times=400, in_channels=2)
+    finally:
+        np.random.default_rng = pin.orig
+    # the same per-time masks, flattened "B (C S)": entry c*200 + s == reference entry s*2 + c
+    assert np.array_equal(c2.numpy().reshape(3, 2, 200), fx["cb_ctx"].reshape(3, 200, 2).transpose(0, 2, 1))
+    assert np.array_equal(t2.numpy().reshape(3, 4, 2, 200), fx["cb_tgt"].reshape(3, 4, 200, 2).transpose(0, 1, 3, 2))
+    assert np.array_equal(v2.numpy().reshape(3, 4, 2, 200), fx["cb_vis"].reshape(3, 4, 200, 2).transpose(0, 1, 3, 2))

@@ -21,6 +21,8 @@ constexpr int NTH = 256;  // threads
 
 struct Geo {
     int N, C_in, L, C, k, stride, L_out, P;
+    long clip_stride;   // elements between consecutive clips of the audio (C_in * L when packed; larger for one channel of a
+                        // multi-channel batch: wavjepa/extractors/audio_channel_feature_extractor.py:163-172 runs x[:, [c]])
 };
 
 template <int TAPS>
@@ -36,7 +38,7 @@ __device__ __forceinline__ int stage_audio(float* xs, const bf16_t* __restrict__
     const int span = min(span_max, g.L - t0 * g.stride);
     for (int ci = 0; ci < g.C_in; ++ci)
         for (int i = threadIdx.x; i < span_max; i += NTH)
-            xs[ci * span_max + i] = i < span ? bf2f(audio[((long)n * g.C_in + ci) * g.L + (long)t0 * g.stride + i]) : 0.f;
+            xs[ci * span_max + i] = i < span ? bf2f(audio[(long)n * g.clip_stride + (long)ci * g.L + (long)t0 * g.stride + i]) : 0.f;
     return span;
 }
 
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __r
     for (int ci = 0; ci < g.C_in; ++ci)
         for (int i = threadIdx.x; i < span; i += 256) {
             const long src = (long)t0 * g.stride + i;
-            xa[ci * span + i] = src < g.L ? audio[((long)n * g.C_in + ci) * g.L + src] : f2bf(0.f);
+            xa[ci * span + i] = src < g.L ? audio[(long)n * g.clip_stride + (long)ci * g.L + src] : f2bf(0.f);
         }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, gq = lane >> 4;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(NTH) void conv0_bwd_rows_kernel(const bf16_t* __res
     for (int idx = threadIdx.x; idx < jn * TAPS; idx += NTH) {
         const int j = idx / TAPS, tp = idx - j * TAPS;
         const int ci = tp / g.k, kk = tp - ci * g.k;
-        xs[idx] = bf2f(audio[((long)n * g.C_in + ci) * g.L + (long)tl[j] * g.stride + kk]);
+        xs[idx] = bf2f(audio[(long)n * g.clip_stride + (long)ci * g.L + (long)tl[j] * g.stride + kk]);
     }
     __syncthreads();
     for (int cb = 0; cb < g.C; cb += 512) {
@@ -406,8 +408,9 @@ __global__ __launch_bounds__(256) void conv0_bwd_final_kernel(const float* __res
     }
 }
 
-inline Geo geo_of(int N, int C_in, int L, int C, int k, int stride, int L_out, int P) {
+inline Geo geo_of(int N, int C_in, int L, int C, int k, int stride, int L_out, int P, long clip_stride) {
     Geo g; g.N = N; g.C_in = C_in; g.L = L; g.C = C; g.k = k; g.stride = stride; g.L_out = L_out; g.P = P;
+    g.clip_stride = clip_stride > 0 ? clip_stride : (long)C_in * L;
     return g;
 }
 
@@ -470,7 +473,7 @@ extern "C" int wj_conv0_gn_gelu_fwd(const wj_conv0_fwd_args* a, void* stream) {
     if (a->N <= 0 || a->C <= 0 || (a->C & 15) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
     if ((a->L_out - 1) * a->stride + a->k > a->L) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
+    const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P, a->audio_clip_stride);
     const int span_max = (TC - 1) * a->stride + a->k;
     if ((a->yx == nullptr) != (a->x1 == nullptr)) return WJ_ERR_ARG;
     const int taps = a->C_in * a->k;
@@ -491,7 +494,7 @@ extern "C" int wj_conv0_gn_gelu_bwd(const wj_conv0_bwd_args* a, void* stream) {
     if (a->N <= 0 || a->C <= 0 || (a->C & 3) || a->L_out <= 0 || a->P < a->L_out) return WJ_ERR_ARG;
     if (a->rows && (!a->row_off || a->max_rows < 0)) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P);
+    const Geo g = geo_of(a->N, a->C_in, a->L, a->C, a->k, a->stride, a->L_out, a->P, a->audio_clip_stride);
     const int taps = a->C_in * a->k;
     switch (taps) {
         case 10: launch_bwd<10>(a, g, s); break;

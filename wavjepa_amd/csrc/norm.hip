@@ -9,8 +9,14 @@ namespace {
 
 constexpr int MAXV = 4;  // float4 chunks per 64-lane row: D <= 1024
 
-__device__ __forceinline__ long remap_row(int m, int seg, int valid) {
-    return seg > 0 ? (long)(m / valid) * seg + (m % valid) : (long)m;
+// token row m -> row of a padded (seg rows per clip, `valid` of them tokens) conv buffer; chan = S > 1: the buffer is
+// channel-major (clip index c*nclips + n) while token m = (n*S + c)*valid + t
+__device__ __forceinline__ long remap_row(int m, int seg, int valid, int chan = 1, int nclips = 0) {
+    if (seg <= 0) return (long)m;
+    const int q = m / valid, t = m - q * valid;
+    if (chan <= 1) return (long)q * seg + t;
+    const int n = q / chan, c = q - n * chan;
+    return ((long)c * nclips + n) * seg + t;
 }
 
 __device__ __forceinline__ f32x4 load4(const void* base, long row, int D, int col, bool is_bf16) {
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
     }
     float gs1 = 0.f, gs2 = 0.f;
     for (int m = m_begin; m < m_end; m += m_step) {
-        const long xr = remap_row(m, a.in_seg, a.in_valid);
+        const long xr = remap_row(m, a.in_seg, a.in_valid, a.in_chan, a.in_chan > 1 ? a.M / (a.in_chan * a.in_valid) : 0);
         f32x4 s[V];
         float sum = 0.f;
 #pragma unroll
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
         for (int u = 0; u < 2; ++u) {
             const bool live = mrow[u] < a.M;
             const int m = live ? mrow[u] : m0;
-            const long xr = remap_row(m, a.in_seg, a.in_valid);
+            const long xr = remap_row(m, a.in_seg, a.in_valid, a.chan, a.chan > 1 ? a.M / (a.chan * a.in_valid) : 0);
             mean[u] = a.mean[m];
             rstd[u] = a.rstd[m];
 #pragma unroll
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
             if (mrow[u] >= a.M) continue;
             const int m = mrow[u];
             const float k1 = c1[u] * invD, k2 = c2[u] * invD;
-            const long orow = remap_row(m, a.out_seg, a.out_valid);
+            const long orow = remap_row(m, a.out_seg, a.out_valid, a.chan, a.chan > 1 ? a.M / (a.chan * a.out_valid) : 0);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const int col = li * 4 + LPR * 4 * j;
@@ -343,6 +349,7 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
     if (!a || !a->x || !a->gamma || !a->beta) return WJ_ERR_ARG;
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if (a->in_seg > 0 && a->in_valid <= 0) return WJ_ERR_ARG;
+    if (a->in_chan > 1 && (a->in_seg <= 0 || a->M % (a->in_chan * a->in_valid))) return WJ_ERR_ARG;
     if (a->group_stats && a->group_rows <= 0) return WJ_ERR_ARG;
     const bool half = (a->D % 128 == 0) && (a->D % 256 != 0) && a->D <= 384;   // 128 / 384: 32 lanes per row
     const int rpw = half ? 2 : 1;
@@ -371,6 +378,7 @@ extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
     if (!a || !a->dy || !a->x || !a->gamma || !a->mean || !a->rstd) return WJ_ERR_ARG;
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if ((a->in_seg > 0 && a->in_valid <= 0) || (a->out_seg > 0 && a->out_valid <= 0)) return WJ_ERR_ARG;
+    if (a->chan > 1 && ((a->in_seg > 0 && a->M % (a->chan * a->in_valid)) || (a->out_seg > 0 && a->M % (a->chan * a->out_valid)))) return WJ_ERR_ARG;
     const int nw = BWD_THREADS / 64;
     const bool half = (a->D % 128 == 0) && (a->D % 256 != 0) && a->D <= 384;
     const int rpw = half ? 2 : 1;

@@ -44,6 +44,8 @@ class EngineConfig:
     h_dec: int
     l_dec: int
     top_k: int
+    streams: int = 1        # audio channels run as separate MONO conv stacks (ConvChannelFeatureExtractor); tokens per clip = streams * frames
+    conv_prefixes: Sequence[str] = ("extract_audio.cnn.",)   # state_dict prefix of every stream's stack (one entry: shared weights)
     ln_eps: float = 1e-6    # transformer layers (reference types/wavjepa_configs.py:37)
     norm_eps: float = 1e-5  # feature_norms / final norms (nn.LayerNorm default)
 
@@ -223,7 +225,11 @@ class JepaEngine:
         self.pos_enc = pos_enc.reshape(-1, cfg.d_enc).contiguous().float().to(self.dev)
         self.pos_dec = pos_dec.reshape(-1, cfg.d_dec).contiguous().float().to(self.dev)
         self.L, self.P = conv_geometry(cfg.n_samples, cfg.conv_spec)
-        self.T = self.L[-1]
+        self.S = max(1, int(cfg.streams))            # channel streams through mono conv stacks
+        self.Tc = self.L[-1]                         # conv frames per stream
+        self.T = self.S * self.Tc                    # tokens per clip: channel-major "B (C S)" flatten
+        self.stacks = list(cfg.conv_prefixes)        # distinct conv stacks; stream c uses stacks[min(c, len - 1)]
+        assert len(self.stacks) in (1, self.S)
         self.C = cfg.conv_spec[-1][0]
         assert all(c == self.C for c, _, _ in cfg.conv_spec), "all conv layers must have the same width"
         assert cfg.d_enc % cfg.h_enc == 0 and cfg.d_dec % cfg.h_dec == 0
@@ -304,15 +310,23 @@ class JepaEngine:
 
     def _alloc_conv_weights(self) -> None:
         C = self.C
-        for l, (_, k, s) in enumerate(self.cfg.conv_spec):
-            if l == 0:
-                continue
-            self._conv_w[f"wp{l}"] = _empty(C, k * C, dtype=torch.bfloat16, device=self.dev)
-            for rho in range(s):
-                U = len(range(rho, k, s))
-                if U > 0:
-                    self._conv_w[f"wd{l}_{rho}"] = _empty(U * C, C, dtype=torch.bfloat16, device=self.dev)
-            self._conv_w[f"dwp{l}"] = torch.zeros(C, k * C, dtype=torch.float32, device=self.dev)
+        for si in range(len(self.stacks)):
+            for l, (_, k, s) in enumerate(self.cfg.conv_spec):
+                if l == 0:
+                    continue
+                self._conv_w[f"{si}:wp{l}"] = _empty(C, k * C, dtype=torch.bfloat16, device=self.dev)
+                for rho in range(s):
+                    U = len(range(rho, k, s))
+                    if U > 0:
+                        self._conv_w[f"{si}:wd{l}_{rho}"] = _empty(U * C, C, dtype=torch.bfloat16, device=self.dev)
+                self._conv_w[f"{si}:dwp{l}"] = torch.zeros(C, k * C, dtype=torch.float32, device=self.dev)
+
+    def _stack_groups(self):
+        """[(stack index, first conv clip, clips)] for the conv GEMMs of a batch of self.N clips: one group over all S*N mono
+        clips when the streams share their weights, one group of N clips per stream otherwise (clips are channel-major)."""
+        if len(self.stacks) == 1:
+            return [(0, 0, self.N * self.S)]
+        return [(c, c * self.N, self.N) for c in range(self.S)]
 
     def prepare_weights(self, force_cast: bool = False) -> None:
         """bf16 shadow copies (when stale) + the GEMM layouts of conv layers 1.. from the fp32 masters."""
@@ -322,15 +336,16 @@ class JepaEngine:
             ops.cast_f32_to_bf16(f.t32, f.t16, f.tn)
             f.bf16_fresh = True
         C = self.C
-        for l, (_, k, s) in enumerate(self.cfg.conv_spec):
-            if l == 0:
-                continue
-            src = f.ptr32(f"extract_audio.cnn.{l}.0.weight")
-            ops.conv_weight_layout(src, self._conv_w[f"wp{l}"], C_out=C, C_in=C, k=k, mode=0)
-            for rho in range(s):
-                U = len(range(rho, k, s))
-                if U > 0:
-                    ops.conv_weight_layout(src, self._conv_w[f"wd{l}_{rho}"], C_out=C, C_in=C, k=k, mode=1, stride=s, rho=rho, U=U)
+        for si, pre in enumerate(self.stacks):
+            for l, (_, k, s) in enumerate(self.cfg.conv_spec):
+                if l == 0:
+                    continue
+                src = f.ptr32(f"{pre}{l}.0.weight")
+                ops.conv_weight_layout(src, self._conv_w[f"{si}:wp{l}"], C_out=C, C_in=C, k=k, mode=0)
+                for rho in range(s):
+                    U = len(range(rho, k, s))
+                    if U > 0:
+                        ops.conv_weight_layout(src, self._conv_w[f"{si}:wd{l}_{rho}"], C_out=C, C_in=C, k=k, mode=1, stride=s, rho=rho, U=U)
 
     # ------------------------------------------------------------------------------------------------ arena
     def _rows(self, nrows: int, width: int, dtype, lead: int = 2, tail: int = 8) -> Tuple[torch.Tensor, int]:
@@ -372,28 +387,29 @@ class JepaEngine:
         self.N, self.G, self.M, self.Mp = N, G, M, Mp
         self._train_alloc = train
         nl = len(c.conv_spec)
+        Nc = N * self.S                               # mono conv clips (channel-major: clip index c*N + n)
         # conv activations (post-GELU, and pre-GELU for layers >= 1) + their gradients
         self.post, self.post_ptr, self.pre, self.pre_ptr = [], [], [None], [0]
         self.dpost, self.dpost_ptr, self.dpre, self.dpre_ptr = [], [], [None], [0]
         for l in range(nl):
-            t, p = self._rows(N * self.P[l], C, bf)
+            t, p = self._rows(Nc * self.P[l], C, bf)
             self.post.append(t); self.post_ptr.append(p)
             if l > 0:
-                t, p = self._rows(N * self.P[l], C, bf)
+                t, p = self._rows(Nc * self.P[l], C, bf)
                 self.pre.append(t); self.pre_ptr.append(p)
             if train:
-                t, p = self._rows(N * self.P[l], C, bf)
+                t, p = self._rows(Nc * self.P[l], C, bf)
                 self.dpost.append(t); self.dpost_ptr.append(p)
                 if l > 0:
-                    t, p = self._rows(N * self.P[l], C, bf)
+                    t, p = self._rows(Nc * self.P[l], C, bf)
                     self.dpre.append(t); self.dpre_ptr.append(p)
-        self.gn_stats = _empty(2, N, C, dtype=f32, device=dev)
+        self.gn_stats = _empty(2, Nc, C, dtype=f32, device=dev)
         taps = c.in_channels * c.conv_spec[0][1]
-        conv0_dims = dict(N=N, C_in=c.in_channels, C=C, k=c.conv_spec[0][1], L_out=self.L[0])
+        conv0_dims = dict(N=N, C_in=c.in_channels, C=C, k=c.conv_spec[0][1], L_out=self.L[0])      # per stream: N clips a call
         self.gn_ws = _empty(ops.workspace_bytes("wj_conv0_gn_gelu_fwd", **conv0_dims) // 4, dtype=f32, device=dev)
         self.gn_ws_b = _empty(ops.workspace_bytes("wj_conv0_gn_gelu_bwd", max_rows=0, **conv0_dims) // 4, dtype=f32, device=dev) if train else None
-        self.gn_yx = _empty(N, C, taps, dtype=f32, device=dev) if train else None     # forward sums the backward needs
-        self.gn_x1 = _empty(N, taps, dtype=f32, device=dev) if train else None
+        self.gn_yx = _empty(Nc, C, taps, dtype=f32, device=dev) if train else None     # forward sums the backward needs
+        self.gn_x1 = _empty(Nc, taps, dtype=f32, device=dev) if train else None
         self.fn_b = _empty(M, C, dtype=bf, device=dev)
         self.fn_mean = _empty(M, dtype=f32, device=dev)
         self.fn_rstd = _empty(M, dtype=f32, device=dev)
@@ -562,20 +578,29 @@ class JepaEngine:
     # ------------------------------------------------------------------------------------------------ front-end
     def _frontend(self, audio: torch.Tensor) -> None:
         """audio bf16 [N, C_in, L] -> lf (fp32) / lf_b (bf16) [N*T, d_enc]   (reference jepa.py:391-396)"""
-        c, f, N, C = self.cfg, self.flat, self.N, self.C
+        c, f, N, C, S = self.cfg, self.flat, self.N, self.C, self.S
         _, k0, s0 = c.conv_spec[0]
-        ops.conv0_fwd(audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
-                      f.ptr32("extract_audio.cnn.0.2.bias"), self.post_ptr[0], self.gn_stats[0], self.gn_stats[1], self.gn_ws,
-                      N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
-                      yx=self.gn_yx if torch.is_grad_enabled() else None, x1=self.gn_x1 if torch.is_grad_enabled() else None)
+        taps = c.in_channels * k0
+        grad = torch.is_grad_enabled()
+        audio_p = audio.data_ptr()
+        for ch in range(S):                               # every stream: N mono clips (ConvFeatureExtractor: one stream, C_in channels)
+            pre = self.stacks[min(ch, len(self.stacks) - 1)]
+            c0 = ch * N                                   # first conv clip of this stream
+            ops.conv0_fwd(audio_p + ch * c.n_samples * 2 if S > 1 else audio, f.ptr16(f"{pre}0.0.weight"), f.ptr32(f"{pre}0.2.weight"),
+                          f.ptr32(f"{pre}0.2.bias"), self.post_ptr[0] + c0 * self.P[0] * C * 2, self.gn_stats[0, c0:], self.gn_stats[1, c0:],
+                          self.gn_ws, N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
+                          yx=self.gn_yx[c0:] if grad else None, x1=self.gn_x1[c0:] if grad else None,
+                          audio_clip_stride=S * c.in_channels * c.n_samples if S > 1 else 0)
         for l in range(1, len(c.conv_spec)):
             _, k, s = c.conv_spec[l]
-            ops.gemm(self.post_ptr[l - 1], self._conv_w[f"wp{l}"], self.pre_ptr[l], C2=self.post_ptr[l], M=N * self.P[l], N=C,
-                     K=k * C, lda=s * C, ldb=k * C, ldc=C, epilogue=ops.EPI_CONV_GELU, seg_rows=self.P[l], seg_valid=self.L[l])
+            for si, c0, nclips in self._stack_groups():
+                ops.gemm(self.post_ptr[l - 1] + c0 * self.P[l - 1] * C * 2, self._conv_w[f"{si}:wp{l}"], self.pre_ptr[l] + c0 * self.P[l] * C * 2,
+                         C2=self.post_ptr[l] + c0 * self.P[l] * C * 2, M=nclips * self.P[l], N=C, K=k * C, lda=s * C, ldb=k * C, ldc=C,
+                         epilogue=ops.EPI_CONV_GELU, seg_rows=self.P[l], seg_valid=self.L[l])
         M, T = self.M, self.T
         ops.layernorm_fwd(self.post_ptr[-1], f.ptr32("feature_norms.weight"), f.ptr32("feature_norms.bias"), M=M, D=C,
                           eps=c.norm_eps, y_bf16=self.fn_b, mean=self.fn_mean, rstd=self.fn_rstd, x_is_bf16=True,
-                          in_seg=self.P[-1], in_valid=T)
+                          in_seg=self.P[-1], in_valid=self.Tc, in_chan=S if S > 1 else 0)
         if self.has_mapper:
             ops.gemm(self.fn_b, f.ptr16("post_extraction_mapper.weight"), self.map_b, M=M, N=c.d_enc, K=C, lda=C, ldb=C,
                      ldc=c.d_enc, bias=f.ptr32("post_extraction_mapper.bias"))
@@ -779,9 +804,10 @@ class JepaEngine:
         else:
             d_fn = dy
         nl = len(c.conv_spec)
+        S, Tc = self.S, self.Tc
         ops.layernorm_bwd(d_fn, self.post_ptr[-1], f.ptr32("feature_norms.weight"), self.fn_mean, self.fn_rstd, M=M, D=C,
                           ds_bf16=self.dpost_ptr[-1], dgamma=f.gptr("feature_norms.weight"), dbeta=f.gptr("feature_norms.bias"),
-                          x_is_bf16=True, in_seg=self.P[-1], in_valid=T, out_seg=self.P[-1], out_valid=T)
+                          x_is_bf16=True, in_seg=self.P[-1], in_valid=Tc, out_seg=self.P[-1], out_valid=Tc, chan=S if S > 1 else 0)
         sparse = rag and self.sparse_conv
         if sparse:
             act_rows = self._conv_rows(plan)
@@ -791,49 +817,61 @@ class JepaEngine:
                 self._conv_grads_dirty = False
         else:
             self._conv_grads_dirty = True
+        groups = self._stack_groups()        # (stack, first conv clip, clips): one group, or one per channel stream
         for l in range(nl - 1, 0, -1):
             _, k, s = c.conv_spec[l]
-            rows = N * self.P[l]
-            dwp = self._conv_w[f"dwp{l}"]
-            dwp.zero_()
-            if sparse:
-                # Only act[l] rows of this layer's output gradient are non-zero.  Every gradient buffer is all-zero outside
-                # the rows written this step (they are cleared again below), so the dgrad taps may read neighbours freely.
-                act, n_act, ext, n_ext = act_rows[l]
-                ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], 0, rows=act, n_rows=n_act, row_elems=C,
-                                  clear_dpost=l < nl - 1)
-                ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=n_act, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
-                         b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, n_act), rowmap=act)
-            else:
-                ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], rows * C)
-                ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=rows, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
-                         b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, rows))
-            ops.conv_weight_layout(dwp, f.gptr(f"extract_audio.cnn.{l}.0.weight"), C_out=C, C_in=C, k=k, mode=2)
             empty_phase = any(len(range(rho, k, s)) == 0 for rho in range(s))
             if empty_phase:
                 self.dpost[l - 1].zero_()
-            for rho in range(s):
-                U = len(range(rho, k, s))
-                if U == 0:
-                    continue
+            for gi, (si, c0, nclips) in enumerate(groups):
+                rows = nclips * self.P[l]
+                r0, r0p = c0 * self.P[l] * C * 2, c0 * self.P[l - 1] * C * 2      # byte offsets of the group's first row (layers l, l-1)
+                dwp = self._conv_w[f"{si}:dwp{l}"]
+                dwp.zero_()
                 if sparse:
-                    ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
-                             M=n_ext, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1, rowmap=ext)
+                    # Only act[l] rows of this layer's output gradient are non-zero.  Every gradient buffer is all-zero outside
+                    # the rows written this step (they are cleared again below), so the dgrad taps may read neighbours freely.
+                    # The lists hold rows of the WHOLE buffer; a group takes its contiguous slice of them.
+                    act, n_act, ext, n_ext = act_rows[l][gi]
+                    ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], 0, rows=act, n_rows=n_act, row_elems=C,
+                                      clear_dpost=l < nl - 1)
+                    if n_act > 0:
+                        ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=n_act, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
+                                 b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, n_act), rowmap=act)
                 else:
-                    ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
-                             M=rows, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1)
-            if sparse:
-                ops.zero_rows(self.dpre_ptr[l], act, n_rows=n_act, row_bytes=C * 2)
+                    ops.gelu_bwd_bf16(self.dpost_ptr[l] + r0, self.pre_ptr[l] + r0, self.dpre_ptr[l] + r0, rows * C)
+                    ops.gemm(self.dpre_ptr[l] + r0, self.post_ptr[l - 1] + r0p, dwp, M=C, N=k * C, K=rows, lda=C, ldb=s * C, ldc=k * C,
+                             a_trans=1, b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, rows))
+                ops.conv_weight_layout(dwp, f.gptr(f"{self.stacks[si]}{l}.0.weight"), C_out=C, C_in=C, k=k, mode=2)
+                for rho in range(s):
+                    U = len(range(rho, k, s))
+                    if U == 0:
+                        continue
+                    if sparse:
+                        if n_ext > 0:
+                            ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"{si}:wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
+                                     M=n_ext, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1, rowmap=ext)
+                    else:
+                        ops.gemm(self.dpre_ptr[l] + r0 - (U - 1) * C * 2, self._conv_w[f"{si}:wd{l}_{rho}"],
+                                 self.dpost_ptr[l - 1] + r0p + rho * C * 2, M=rows, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1)
+                if sparse:
+                    ops.zero_rows(self.dpre_ptr[l], act, n_rows=n_act, row_bytes=C * 2)
         _, k0, s0 = c.conv_spec[0]
-        ops.conv0_bwd(self.audio, f.ptr16("extract_audio.cnn.0.0.weight"), f.ptr32("extract_audio.cnn.0.2.weight"),
-                      f.ptr32("extract_audio.cnn.0.2.bias"), self.gn_stats[0], self.gn_stats[1], self.dpost_ptr[0],
-                      f.gptr("extract_audio.cnn.0.0.weight"), f.gptr("extract_audio.cnn.0.2.weight"),
-                      f.gptr("extract_audio.cnn.0.2.bias"), self.gn_ws_b, yx=self.gn_yx, x1=self.gn_x1, N=N, C_in=c.in_channels,
-                      L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
-                      **(dict(rows=act_rows[0][0], row_off=act_rows[0][2], max_rows=act_rows[0][3]) if sparse else {}))
-        if sparse:
-            act, n_act, _, _ = act_rows[0]
-            ops.zero_rows(self.dpost_ptr[0], act, n_rows=n_act, row_bytes=C * 2)
+        audio_p = self.audio.data_ptr()
+        for ch in range(S):                  # layer 0: one call per stream (N mono clips each; ConvFeatureExtractor: one stream)
+            pre = self.stacks[min(ch, len(self.stacks) - 1)]
+            c0 = ch * N
+            lists = {}
+            if sparse:
+                rows0, n0, off0, max0 = act_rows[0][ch]
+                lists = dict(rows=rows0, row_off=off0, max_rows=max0)
+            ops.conv0_bwd(audio_p + ch * c.n_samples * 2 if S > 1 else self.audio, f.ptr16(f"{pre}0.0.weight"), f.ptr32(f"{pre}0.2.weight"),
+                          f.ptr32(f"{pre}0.2.bias"), self.gn_stats[0, c0:], self.gn_stats[1, c0:], self.dpost_ptr[0] + c0 * self.P[0] * C * 2,
+                          f.gptr(f"{pre}0.0.weight"), f.gptr(f"{pre}0.2.weight"), f.gptr(f"{pre}0.2.bias"), self.gn_ws_b,
+                          yx=self.gn_yx[c0:], x1=self.gn_x1[c0:], N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0,
+                          L_out=self.L[0], P=self.P[0], audio_clip_stride=S * c.in_channels * c.n_samples if S > 1 else 0, **lists)
+            if sparse:
+                ops.zero_rows(self.dpost_ptr[0] + c0 * self.P[0] * C * 2, rows0, n_rows=n0, row_bytes=C * 2)
         self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
         for tag in ("enc", "dec"):
             self.bw[tag]["used"] = [False, False]
@@ -841,21 +879,46 @@ class JepaEngine:
             on_grads_ready("front")
 
     def _conv_rows(self, plan: MaskPlan):
-        """Device copies of conv_active_rows for this plan (cached on the plan: mask sets are reused by the data source)."""
+        """Device copies of conv_active_rows for this plan (cached on the plan: mask sets are reused by the data source).
+        {l >= 1: [per stack group (act, n_act, ext, n_ext)]} with rows of the WHOLE layer buffer (a group's rows are a contiguous
+        slice of the ascending list: conv clips are channel-major), {0: [per stream (rows, n, row_off, max_rows)]} with rows
+        relative to the stream's first clip (one conv0 call per stream)."""
         cached = getattr(plan, "_conv_rows", None)
-        if cached is not None and cached[0] == (self.N, tuple(self.P)):
+        if cached is not None and cached[0] == (self.N, self.S, len(self.stacks), tuple(self.P)):
             return cached[1]
+        N, S = self.N, self.S
         keep = (plan.ctx_u8.cpu().numpy() == 0) if plan.ctx_np is None else ~plan.ctx_np
+        if S > 1:                            # tokens (n, c, t) -> conv clip c*N + n
+            keep = np.ascontiguousarray(keep.reshape(N, S, self.Tc).transpose(1, 0, 2)).reshape(S * N, self.Tc)
         lists = conv_active_rows(keep, self.P, self.cfg.conv_spec)
         pad = np.zeros(256, np.int32)        # the k-gather GEMM prefetches indices up to 256 entries past the end
 
         def up(a):
             return torch.from_numpy(np.concatenate([a, pad])).to(self.dev, non_blocking=True)
 
-        out = {l: (up(act), int(act.size), up(ext), int(ext.size)) for l, (act, ext) in lists.items() if l > 0}
+        groups = self._stack_groups()
+        out = {}
+        for l, (act, ext) in lists.items():
+            if l == 0:
+                continue
+            d_act, d_ext = up(act), up(ext)
+            per = []
+            for _, c0, nclips in groups:
+                lo, hi = c0 * self.P[l], (c0 + nclips) * self.P[l]
+                a0, a1 = np.searchsorted(act, [lo, hi])
+                e0, e1 = np.searchsorted(ext, [lo, hi])
+                per.append((d_act.data_ptr() + 4 * int(a0), int(a1 - a0), d_ext.data_ptr() + 4 * int(e0), int(e1 - e0)))
+            out[l] = per
+            out[("keep", l)] = (d_act, d_ext)        # owners of the pointers above
         act0, off0 = lists[0]
-        out[0] = (up(act0), int(act0.size), up(off0), int(np.diff(off0).max()) if off0.size > 1 else 0)   # (rows, n, row_off, max_rows)
-        plan._conv_rows = ((self.N, tuple(self.P)), out)
+        per0 = []
+        for ch in range(S):
+            lo, hi = int(off0[ch * N]), int(off0[(ch + 1) * N])
+            rows = (act0[lo:hi] - ch * N * self.P[0]).astype(np.int32)
+            off = (off0[ch * N:(ch + 1) * N + 1] - lo).astype(np.int32)
+            per0.append((up(rows), int(rows.size), up(off), int(np.diff(off).max()) if off.size > 1 else 0))
+        out[0] = per0
+        plan._conv_rows = ((self.N, self.S, len(self.stacks), tuple(self.P)), out)
         return out
 
     # ------------------------------------------------------------------------------------------------ EMA / inference

@@ -135,6 +135,10 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        loss = None
+        if closure is not None:          # Lightning's automatic optimisation hands training_step + backward over as a closure
+            with torch.enable_grad():
+                loss = closure()
         m = self._module
         m._ensure_engine()
         flat = m._flat
@@ -150,7 +154,7 @@ class FusedAdamW(torch.optim.Optimizer):
                        beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._t,
                        max_norm=self.max_grad_norm, sumsq=self._sumsq if self.max_grad_norm > 0 else None, p_bf16=flat.p16)
         m._student_bf16_fresh = True
-        return None
+        return loss
 
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the last step's gradients (device scalar; no sync)."""
@@ -191,7 +195,23 @@ class _NullTrainer:
     max_steps = 375000
 
 
-class JEPA(nn.Module):
+# The reference's JEPA is a pytorch_lightning.LightningModule (reference jepa.py:24).  When Lightning is importable this class
+# derives from it too, so pl.Trainer.fit(model, datamodule) accepts it (hooks: on_after_batch_transfer, training_step,
+# configure_optimizers; `hparams` through save_hyperparameters; `global_step` / `trainer` / `device` / `log_dict` are Lightning's
+# own).  Without Lightning (this image ships none) it is a plain nn.Module that provides those attributes itself and
+# wavjepa_amd.trainer.Trainer drives it.
+try:                                         # pragma: no cover - depends on the environment
+    import pytorch_lightning as _pl
+except Exception:                            # noqa: BLE001
+    try:
+        import lightning.pytorch as _pl
+    except Exception:                        # noqa: BLE001
+        _pl = None
+HAS_LIGHTNING = _pl is not None
+_ModuleBase = _pl.LightningModule if HAS_LIGHTNING else nn.Module
+
+
+class JEPA(_ModuleBase):
     """Joint-Embedding Predictive Architecture for waveforms (student encoder + predictor vs EMA teacher)."""
 
     def __init__(self, feature_extractor: Extractor, transformer_encoder_layers_cfg: TransformerLayerCFG,
@@ -210,14 +230,18 @@ class JEPA(nn.Module):
         self.total_patches = feature_extractor.total_patches(self.target_length)
         self.use_compiled_forward = False            # there is no tracing compiler on this path: kernels are hand-written
         self.use_gradient_checkpointing = False      # the reference's flag is off by default and buggy (drops the mask)
-        self.hparams = _AttrDict(lr=lr, adam_betas=tuple(adam_betas), adam_eps=adam_eps, adam_weight_decay=adam_weight_decay,
-                                 ema_decay=ema_decay, ema_end_decay=ema_end_decay, ema_anneal_end_step=ema_anneal_end_step,
-                                 average_top_k_layers=average_top_k_layers, resample_sr=resample_sr,
-                                 process_audio_seconds=process_audio_seconds, nr_samples_per_audio=nr_samples_per_audio,
-                                 compile_modules=compile_modules, size=size, warmup_steps=warmup_steps,
-                                 decoder_embedding_dim=decoder_embedding_dim)
-        self.global_step = 0
-        self.trainer = _NullTrainer()
+        if HAS_LIGHTNING:        # as the reference does (jepa.py:105-107): hyper-parameters into the checkpoint
+            self.save_hyperparameters(ignore=["feature_encoder", "feature_extractor", "loss_fn"])
+            self.hparams["adam_betas"] = tuple(adam_betas)
+        else:
+            self.hparams = _AttrDict(lr=lr, adam_betas=tuple(adam_betas), adam_eps=adam_eps, adam_weight_decay=adam_weight_decay,
+                                     ema_decay=ema_decay, ema_end_decay=ema_end_decay, ema_anneal_end_step=ema_anneal_end_step,
+                                     average_top_k_layers=average_top_k_layers, resample_sr=resample_sr,
+                                     process_audio_seconds=process_audio_seconds, nr_samples_per_audio=nr_samples_per_audio,
+                                     compile_modules=compile_modules, size=size, warmup_steps=warmup_steps,
+                                     decoder_embedding_dim=decoder_embedding_dim)
+            self.global_step = 0
+            self.trainer = _NullTrainer()
         self.extract_audio = feature_extractor
         self.feature_norms = nn.LayerNorm(self.extract_audio.embedding_dim)
         self.loss_fn = loss_fn
@@ -274,9 +298,23 @@ class JEPA(nn.Module):
         self.teacher_encoder.requires_grad_(False)
 
     # ------------------------------------------------------------------------------------------------ device / engine
-    @property
-    def device(self) -> torch.device:
-        return self.mask_token.device
+    if not HAS_LIGHTNING:        # Lightning provides `device`, `log_dict`, `global_step` and `trainer` itself
+        @property
+        def device(self) -> torch.device:
+            return self.mask_token.device
+
+        def log_dict(self, data: Dict[str, Any], **kw) -> None:
+            self._logged = dict(data)
+            log = getattr(self.trainer, "log_dict", None)
+            if log is not None:
+                log(data, **kw)
+
+    def _max_steps(self) -> int:
+        try:
+            steps = int(self.trainer.max_steps)
+        except (RuntimeError, AttributeError, TypeError):      # Lightning: not attached to a Trainer yet
+            steps = -1
+        return steps if steps > 0 else _NullTrainer.max_steps
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -299,7 +337,14 @@ class JEPA(nn.Module):
         if self.device.type != "cuda":
             raise RuntimeError("wavjepa_amd.JEPA computes only on an MI355X: move the module with .cuda() first "
                                "(there is no CPU fallback on the product path)")
-        spec = self.extract_audio.conv_layers_spec
+        ext = self.extract_audio
+        spec = ext.conv_layers_spec
+        if hasattr(ext, "cnns"):             # ConvChannelFeatureExtractor: every audio channel through a mono conv stack
+            streams, conv_in = ext.in_channels, 1
+            prefixes = ["extract_audio.cnns.0."] if ext.weight_sharing else [f"extract_audio.cnns.{c}." for c in range(streams)]
+        else:
+            streams, conv_in, prefixes = 1, ext.in_channels, ["extract_audio.cnn."]
+        self._audio_channels = ext.in_channels
         self._flat = FlatParams(self, self.device)
         carry = getattr(self, "_adam_carry", None)
         if carry is not None:
@@ -307,7 +352,7 @@ class JEPA(nn.Module):
                 raise RuntimeError("optimiser state exists for a different parameter layout; rebuild the optimiser")
             self._flat.adam_m, self._flat.adam_v = carry[0].to(self.device), carry[1].to(self.device)
             self._adam_carry = None
-        cfg = EngineConfig(conv_spec=spec, in_channels=self.extract_audio.in_channels, n_samples=self.target_length,
+        cfg = EngineConfig(conv_spec=spec, in_channels=conv_in, streams=streams, conv_prefixes=prefixes, n_samples=self.target_length,
                            d_enc=self.encoder_embedding_dim, h_enc=self.n_encoder_heads, l_enc=self.encoder.num_layers,
                            d_dec=self.decoder_embedding_dim, h_dec=self.n_decoder_heads, l_dec=self.decoder.num_layers,
                            top_k=int(self.hparams.average_top_k_layers), ln_eps=self.encoder.layer_norm_eps)
@@ -343,14 +388,8 @@ class JEPA(nn.Module):
         optimizer = FusedAdamW(self, lr=self.hparams.lr, betas=self.hparams.adam_betas, eps=self.hparams.adam_eps,
                                weight_decay=self.hparams.adam_weight_decay)
         sched = cosine_schedule_with_warmup(optimizer, num_warmup_steps=int(self.hparams.warmup_steps),
-                                            num_training_steps=int(self.trainer.max_steps))
+                                            num_training_steps=self._max_steps())
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": sched, "interval": "step"}}
-
-    def log_dict(self, data: Dict[str, Any], **kw) -> None:
-        self._logged = dict(data)
-        log = getattr(self.trainer, "log_dict", None)
-        if log is not None:
-            log(data, **kw)
 
     # ------------------------------------------------------------------------------------------------ batch preparation
     def on_after_batch_transfer(self, batch, dataloader_idx: int = 0):
@@ -387,6 +426,8 @@ class JEPA(nn.Module):
         audio = audio.to(self.device, dtype=torch.bfloat16).contiguous()
         if audio.shape[-1] != self.target_length:
             raise ValueError(f"expected {self.target_length} samples per clip, got {audio.shape[-1]}")
+        if audio.shape[1] != self.extract_audio.in_channels:
+            raise ValueError(f"expected {self.extract_audio.in_channels} audio channel(s), got {audio.shape[1]}")
         plan = ctx_masks if isinstance(ctx_masks, MaskPlan) else make_mask_plan(ctx_masks, target_indices, ctx_and_target_masks, self.device)
         self._prepare_weights()
         eng.forward(audio, plan)

@@ -101,20 +101,21 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 # ---------------------------------------------------------------------------------------------------------- norms
 def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, r: Ptr = None, y_f32: Ptr = None,
                   y_bf16: Ptr = None, mean: Ptr = None, rstd: Ptr = None, x_is_bf16: bool = False, in_seg: int = 0,
-                  in_valid: int = 0, group_stats: Ptr = None, group_rows: int = 0, stream: Optional[int] = None) -> None:
+                  in_valid: int = 0, group_stats: Ptr = None, group_rows: int = 0, in_chan: int = 0,
+                  stream: Optional[int] = None) -> None:
     _run("wj_layernorm_fwd", "wj_ln_fwd_args", stream, x=_p(x), r=_p(r), gamma=_p(gamma), beta=_p(beta), y_f32=_p(y_f32),
          y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), group_stats=_p(group_stats), M=M, D=D, x_is_bf16=int(x_is_bf16),
-         in_seg=in_seg, in_valid=in_valid, group_rows=group_rows, eps=eps)
+         in_seg=in_seg, in_valid=in_valid, group_rows=group_rows, in_chan=in_chan, eps=eps)
 
 
 def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
                   ds_f32: Ptr = None, ds_bf16: Ptr = None, dgamma: Ptr = None, dbeta: Ptr = None, dbias: Ptr = None,
                   x_is_bf16: bool = False, in_seg: int = 0, in_valid: int = 0, out_seg: int = 0, out_valid: int = 0,
-                  workspace: Ptr = None, stream: Optional[int] = None) -> None:
+                  chan: int = 0, workspace: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_layernorm_bwd", "wj_ln_bwd_args", stream, dy=_p(dy), dy2=_p(dy2), x=_p(x), r=_p(r), gamma=_p(gamma),
          mean=_p(mean), rstd=_p(rstd), ds_f32=_p(ds_f32), ds_bf16=_p(ds_bf16), dgamma=_p(dgamma), dbeta=_p(dbeta),
          dbias=_p(dbias), workspace=_p(workspace), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, out_seg=out_seg,
-         out_valid=out_valid)
+         out_valid=out_valid, chan=chan)
 
 
 def colsum_bf16(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[int] = None) -> None:
@@ -143,20 +144,21 @@ def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: i
 # ---------------------------------------------------------------------------------------------------------- conv front-end
 def conv0_fwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, act: Ptr, mean: Ptr, rstd: Ptr, workspace: Ptr, *, N: int,
               C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int, eps: float = 1e-5, yx: Ptr = None,
-              x1: Ptr = None, stream: Optional[int] = None) -> None:
+              x1: Ptr = None, audio_clip_stride: int = 0, stream: Optional[int] = None) -> None:
     _run("wj_conv0_gn_gelu_fwd", "wj_conv0_fwd_args", stream, audio=_p(audio), w=_p(w), gamma=_p(gamma), beta=_p(beta),
          act=_p(act), mean=_p(mean), rstd=_p(rstd), workspace=_p(workspace), yx=_p(yx), x1=_p(x1), N=N, C_in=C_in, L=L, C=C,
-         k=k, stride=stride, L_out=L_out, P=P, eps=eps)
+         k=k, stride=stride, L_out=L_out, P=P, eps=eps, audio_clip_stride=audio_clip_stride)
 
 
 def conv0_bwd(audio: Ptr, w: Ptr, gamma: Ptr, beta: Ptr, mean: Ptr, rstd: Ptr, dact: Ptr, dw: Ptr, dgamma: Ptr, dbeta: Ptr,
               workspace: Ptr, *, yx: Ptr, x1: Ptr, N: int, C_in: int, L: int, C: int, k: int, stride: int, L_out: int, P: int,
-              rows: Ptr = None, row_off: Ptr = None, max_rows: int = 0, stream: Optional[int] = None) -> None:
+              rows: Ptr = None, row_off: Ptr = None, max_rows: int = 0, audio_clip_stride: int = 0,
+              stream: Optional[int] = None) -> None:
     """rows / row_off / max_rows: read the output gradient on the listed rows only (see include/wavjepa_hip.h)."""
     _run("wj_conv0_gn_gelu_bwd", "wj_conv0_bwd_args", stream, audio=_p(audio), w=_p(w), gamma=_p(gamma), beta=_p(beta),
          mean=_p(mean), rstd=_p(rstd), dact=_p(dact), yx=_p(yx), x1=_p(x1), rows=_p(rows), row_off=_p(row_off), dw=_p(dw),
          dgamma=_p(dgamma), dbeta=_p(dbeta), workspace=_p(workspace), N=N, C_in=C_in, L=L, C=C, k=k, stride=stride, L_out=L_out,
-         P=P, max_rows=max_rows)
+         P=P, max_rows=max_rows, audio_clip_stride=audio_clip_stride)
 
 
 def gelu_bwd_bf16(dpost: Ptr, pre: Ptr, dpre: Ptr, n: int, *, rows: Ptr = None, n_rows: int = 0, row_elems: int = 0,
