@@ -40,15 +40,20 @@ template <int BN> struct Cfg {
     static constexpr int A_BYTES = BM * BK * 2;                        // 16384
     static constexpr int B_BYTES = BN * BK * 2;                        // 16384 / 8192
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;              // 32768 / 24576
-    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;             // 131072 / 73728
+    static constexpr int RING_BYTES = STAGES * STAGE_BYTES;            // 131072 / 73728
     static constexpr int LOADS_PER_TILE = STAGE_BYTES / 1024 / 8;      // LDS-DMA instructions per wave per K tile: 4 / 3
     static constexpr int WAVES_N = BN / 64;                            // 4 / 2
     static constexpr int WAVES_M = 8 / WAVES_N;                        // 2 / 4
     static constexpr int MI = BM / WAVES_M / 16;                       // m-fragments per wave: 8 / 4
     static constexpr int CP_BF16 = BN * 2 + 16;                        // C staging pitch, bf16
     static constexpr int CP_F32 = BN * 4 + 16;                         // fp32
-    static constexpr int RC_BF16 = BN == 256 ? 128 : 256;              // rows staged per chunk (fits LDS_BYTES)
-    static constexpr int RC_F32 = BN == 256 ? 64 : 128;
+    // C staging: rows per chunk.  The 256-wide tile asks for 132 KiB of LDS (still one workgroup per CU) so that a bf16 tile is
+    // staged in ONE pass -- all eight waves write at once, one barrier, whole-row stores -- and an fp32 tile in two
+    // (stamps: the two-pass / four-pass forms took 8.6 k cycles per tile, 18-24 % of a K = 768 / 384 tile's lifetime)
+    static constexpr int RC_BF16 = 256;
+    static constexpr int RC_F32 = 128;
+    static constexpr int EPI_BYTES = RC_BF16 * CP_BF16 > RC_F32 * CP_F32 ? RC_BF16 * CP_BF16 : RC_F32 * CP_F32;   // 135168 / 69632
+    static constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
@@ -205,7 +210,6 @@ struct EpiArgs {
     long ldc;
     int seg_rows, seg_valid;
     float alpha;
-    int desync;              // eight-phase schedule: start-up stagger of the first round of workgroups (see the kernel)
     const int32_t* rowmap;   // gather forms: storage row of logical row m (GATHER 1) / of logical k (GATHER 2)
 };
 
@@ -446,14 +450,6 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     };
 
     if constexpr (SCHED == 2) {
-        // De-synchronise the chip.  With one workgroup per CU every CU would compute, then every CU would write its 128 KiB of
-        // C at the same time: the HBM write burst of a round (33 MB) is then not overlapped with anything.  The workgroups of
-        // the FIRST round start a fraction of a tile apart (4 groups of CUs), and because a CU picks up its next workgroup when
-        // the previous one leaves, the offset persists: one group's C burst runs under the other groups' MFMA loops.
-        if (e.desync > 0 && blockIdx.x < 256) {
-            const int ph = (blockIdx.x >> 3) & ((e.desync >> 8) ? 7 : 3);
-            for (int w = 0; w < ph * (e.desync & 255); ++w) __builtin_amdgcn_s_sleep(8);     // 512 clocks each
-        }
         eight_phase_loop(acc, smem, A, B, lda, ldb, m0, n0, M, N, K, wave, lane);
     } else if (nkt > 0) {
 #pragma unroll
@@ -777,11 +773,6 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
     e.rowmap = a->rowmap;
-    {   // start-up stagger in units of 2048 clocks per group step: a quarter of a tile's main loop (~2100 clocks per 64-deep K tile)
-        static const int dq = [] { const char* v = getenv("WJ_GEMM_DESYNC"); return v ? atoi(v) : 4; }();
-        e.desync = dq;
-        if (tiles_m * tiles_n * split <= 256) e.desync = 0;      // a single round: nothing to overlap with
-    }
     auto kern = gemm3_kernel<AT, BT, EPI, BN, SCHED, GATHER>;
     constexpr int lds = Cfg<BN>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
