@@ -35,10 +35,16 @@ import torch.distributed as dist  # noqa: E402
 
 CONV_SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)]
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; /opt/skills/guides/MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
+MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense, block-scaled (MX) e4m3: the scaled MFMA form is the one that runs at 2x the bf16 rate
+WORKLOADS = {   # name: (seconds per clip, fp8 forward GEMMs)
+    "2s-bf16": (2.01, False),    # BASELINE config 2 / 3: the headline metric
+    "4s-bf16": (4.01, False),    # 400 tokens, bf16
+    "4s-fp8": (4.01, True),      # BASELINE config 5: 400 tokens, MX fp8 forward GEMMs
+}
 STEP_GFLOP_PER_CLIP = 283.7      # dense algorithmic FLOPs of one step per clip (fwd 118.2 + bwd 165.5)
 
 
-def build_model(device, seed: int):
+def build_model(device, seed: int, seconds: float = 2.01):
     from wavjepa_amd.extractors import ConvFeatureExtractor
     from wavjepa_amd.jepa import JEPA
     from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
@@ -47,7 +53,7 @@ def build_model(device, seed: int):
     model = JEPA(feature_extractor=ext, transformer_encoder_cfg=TransformerEncoderCFG.create(),
                  transformer_encoder_layers_cfg=TransformerLayerCFG.create(), transformer_decoder_cfg=TransformerEncoderCFG.create(),
                  transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384), lr=4e-4, adam_betas=(0.9, 0.98),
-                 adam_weight_decay=0.04, resample_sr=16000, process_audio_seconds=2.01, nr_samples_per_audio=8,
+                 adam_weight_decay=0.04, resample_sr=16000, process_audio_seconds=seconds, nr_samples_per_audio=8,
                  average_top_k_layers=8, size="base")
     return model.to(device)
 
@@ -90,7 +96,13 @@ def profile_one_step(runner, source, step_idx: int):
     classes, shapes = {}, {}
     for fn, f, e0, e1 in recs:
         ms = e0.elapsed_time(e1)
-        if fn == "wj_gemm_bf16":
+        if fn == "wj_gemm_mxfp8":
+            name, flops = f"gemm_mxfp8<NN,{ {0: 'BF16', 1: 'BIAS_GELU2', 6: 'BIAS_GELU'}[f['epilogue']] }>", 2.0 * f["M"] * f["N"] * f["K"]
+            nbytes = 1.03 * f["K"] * (f["M"] + f["N"]) + 2.0 * f["M"] * f["N"] * (2 if f["epilogue"] == 1 else 1)
+            key = f"{name} M={f['M']} N={f['N']} K={f['K']}"
+            sh = shapes.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
+            sh["ms"] += ms; sh["flops"] += flops; sh["launches"] += 1
+        elif fn == "wj_gemm_bf16":
             name, flops = gemm_kernel_name(f), 2.0 * f["M"] * f["N"] * f["K"]
             ep = f["epilogue"]
             outb = 4 if ep in (3, 4) else 2
@@ -211,6 +223,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips-per-gpu", type=int, default=256)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="2s-bf16",
+                    help="2s-bf16 = the headline metric (BASELINE config 2/3); 4s-fp8 = BASELINE config 5 (400 tokens, MX fp8 forward GEMMs)")
     ap.add_argument("--dense-steps", type=int, default=5, help="extra timed steps with the dense (non-ragged) shapes; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -227,7 +241,9 @@ def main():
     S = 8
     if args.clips_per_gpu % S:
         raise SystemExit("--clips-per-gpu must be a multiple of 8 (8 crops per source audio)")
-    model = build_model(device, seed=42)          # same init on every rank (+ broadcast from rank 0 in StepRunner)
+    seconds, fp8 = WORKLOADS[args.workload]
+    model = build_model(device, seed=42, seconds=seconds)          # same init on every rank (+ broadcast from rank 0 in StepRunner)
+    model._ensure_engine().fp8 = fp8
     model.trainer.max_steps = 375000
     masker = TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10, target_prob=0.25,
                                     target_length=10, ratio_cutoff=0.1)      # configs/masker/AudioSet.yaml
@@ -306,11 +322,18 @@ def main():
         executed_gflop = sum(v["flops"] for v in gemms.values()) / 1e9      # GEMM flops one step actually executes
         if gemms:
             name, c = max(gemms.items(), key=lambda kv: kv[1]["ms"])
+            if fp8:                    # config 5: the roofline of the fp8 GEMM family, against the dense fp8 MFMA peak
+                f8 = {k: v for k, v in gemms.items() if k.startswith("gemm_mxfp8")}
+                name = max(f8.items(), key=lambda kv: kv[1]["ms"])[0]
+                c = dict(ms=sum(v["ms"] for v in f8.values()), flops=sum(v["flops"] for v in f8.values()),
+                         launches=sum(v["launches"] for v in f8.values()), bytes=sum(v["bytes"] for v in f8.values()))
+                name = "gemm_mxfp8<NN,*> (all epilogues; largest: " + name + ")"
+            peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS
             all_ms = sum(v["ms"] for v in gemms.values())
             all_fl = sum(v["flops"] for v in gemms.values())
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic_for(name), launches_per_step=c["launches"],
+            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 4), traffic=None if fp8 else pmc_traffic_for(name), launches_per_step=c["launches"],
                             avg_launch_ms=round(c["ms"] / c["launches"], 4),
                             gflop_per_launch=round(c["flops"] / c["launches"] / 1e9, 2),
                             algorithmic_bytes_per_launch=int(c["bytes"] / c["launches"]),   # operands once + outputs (+ addends)
@@ -323,10 +346,13 @@ def main():
         line = {
             "metric": "jepa_pretrain_clips_per_sec", "value": round(value, 1), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1000, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "WavJEPA-base JEPA pre-training step, 2.01 s @16 kHz white-noise clips (32159 samples -> 200 tokens), "
-                                   f"{args.clips_per_gpu} clips per GPU (32 sources x 8 crops), AudioSet masker, random-init weights",
-                       "global_batch": args.clips_per_gpu * world, "seq_len": 200, "parallelism": f"dp{world}",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 (MX) forward GEMMs, bf16 elsewhere" if fp8 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"WavJEPA-base JEPA pre-training step, {seconds} s @16 kHz white-noise clips ({model.target_length} samples -> "
+                                   f"{model.total_patches} tokens), {args.clips_per_gpu} clips per GPU ({args.clips_per_gpu // 8} sources x 8 crops), "
+                                   "AudioSet masker, random-init weights" + (", MX fp8 forward GEMMs (BASELINE config 5)" if fp8 else ""),
+                       "workload_name": args.workload,
+                       "global_batch": args.clips_per_gpu * world, "seq_len": model.total_patches, "parallelism": f"dp{world}",
                        # student / predictor run on their visible tokens only unless WJ_RAGGED=0 (same loss and gradients:
                        # the dropped rows are key-masked and carry zero loss weight on the reference)
                        "token_execution": "ragged" if model._engine.ragged else "dense",
@@ -336,7 +362,7 @@ def main():
             "model_tflops_per_gpu": None if executed_gflop is None else round(executed_gflop / (elapsed / args.steps) / 1000, 1),
             # dense model FLOPs exactly as the reference computes them (283.7 GFLOP per clip and step), independent
             # of the rows the ragged execution does not compute -- the rate a dense-shape implementation would need to keep up
-            "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1),
+            "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1) if seconds < 3 else None,
             # the same step computed with the reference's dense shapes (WJ_RAGGED=0 equivalent), this run
             "dense_ms_per_step": None if dense_ms is None else round(dense_ms, 2),
             "dense_clips_per_s": None if dense_ms is None else round(args.clips_per_gpu * world / (dense_ms / 1000), 1),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 4
+#define WJ_ABI_VERSION 5
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -68,6 +68,40 @@ typedef struct {
     float alpha;
 } wj_gemm_args;
 int wj_gemm_bf16(const wj_gemm_args*, void* stream);
+/* ------------------------------------------------------------------------------------------------------------
+ * MX fp8 GEMM (BASELINE config 5; build-defined numerics, the reference has no fp8): C[M,N] = A . B^T with A [M][K], B [N][K] OCP
+ * e4m3 bytes (K contiguous, lda / ldb in BYTES, multiples of 16) and one E8M0 scale per 32 consecutive k of every row:
+ *   x[r][k] = e4m3(q[r][k]) * 2^(s[r][k / 32] - 127).
+ * Scales are stored [K / 128][ld_scale] dwords (dword (kt, r): byte b = scale of k block 4 kt + b of row r; ld_scale >= rows, and
+ * the array carries 256 dwords of readable padding after the last row) -- what wj_quantize_mxfp8 writes.  fp32 accumulation on
+ * v_mfma_scale_f32_16x16x128_f8f6f4; epilogues WJ_EPI_BF16 (+ bias), WJ_EPI_BIAS_GELU2, WJ_EPI_BIAS_GELU.  K % 256 == 0.
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const void* A;
+    const void* B;
+    const void* scale_a;
+    const void* scale_b;
+    void* C;
+    void* C2;
+    const float* bias;
+    int64_t lda, ldb, ldc;
+    int64_t ld_scale_a, ld_scale_b;
+    int32_t M, N, K;
+    int32_t epilogue;
+} wj_gemm_fp8_args;
+int wj_gemm_mxfp8(const wj_gemm_fp8_args*, void* stream);
+
+/* q (e4m3 bytes, [M][ldq]) and block scales ([K / 128][ld_scale] dwords as above) of a bf16 matrix x [M][ldx], K % 128 == 0.
+ * Per 32-element block: s = ceil(log2(amax / 448)) (no element saturates; an all-zero block gets s = 0), q = RNE(x * 2^-s). */
+typedef struct {
+    const void* x;
+    void* q;
+    void* scales;
+    int64_t ldx, ldq, ld_scale;
+    int32_t M, K;
+} wj_quantize_fp8_args;
+int wj_quantize_mxfp8(const wj_quantize_fp8_args*, void* stream);
+
 /* Tuning / A-B hook (tools/gemm_bench.py, tests): force the tile/schedule variant of wj_gemm_bf16 (0..3, see csrc/gemm.hip;
  * a variant that cannot run a shape falls back to variant 0); -1 = automatic selection.  Returns the previous setting.
  * Same effect as the WJ_GEMM_VARIANT environment variable.  Results do not depend on the variant beyond fp32 summation order. */

@@ -381,6 +381,54 @@ def test_forward_backward_parity_channel_extractor(stacks, ragged):
     assert tok.shape == want.shape == (3, 198, 64) and rel(tok.float(), want.float()) < 2e-2
 
 
+def test_fp8_forward_path_base_model_400_tokens_vs_bf16_path():
+    """BASELINE config 5 (WavJEPA-base, 4.01 s clips -> 400 tokens, fp8 MFMA on the attention-projection / MLP GEMMs).  The reference
+    has no fp8, so the yardstick is this library's own bf16 path on the same weights and inputs (itself checked against the oracle at
+    400 tokens by test_forward_backward_parity_400_tokens and, on the base model, by test_forward_backward_parity[base-*]): MX fp8
+    (e4m3 elements, one power-of-two scale per 32) perturbs every quantised GEMM operand by <= 2^-4 relative per element.
+    Stated tolerances (measured: 1.2e-3 / 3.9e-2 / 3.4-6.6e-2): loss within 1e-2 relative, teacher targets within 8e-2 relative L2,
+    parameter-gradient groups within 0.15 relative L2 (the backward differentiates the bf16 graph from fp8-forward activations).
+    Also runs the 400-token parity of the bf16 path on the BASE model against the oracle (the 2-layer model has it above)."""
+    m, P = build(BASE, seconds=4.01, tokens=400)
+    assert m.total_patches == 400
+    fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "masks.npz")))
+    ctx, tgt, vis = (torch.from_numpy(fx[k][:2]) for k in ("as400_ctx", "as400_tgt", "as400_vis"))
+    audio = torch.from_numpy(synth.synth_audio(2, 1, 64160, seed=41)).to(torch.bfloat16).to(dev())
+    eng = m._ensure_engine()
+    res = {}
+    for mode in ("bf16", "fp8"):
+        eng.fp8 = mode == "fp8"
+        out = m(audio, ctx, tgt, vis)
+        out["loss"].backward()
+        res[mode] = dict(loss=float(out["loss"].detach()), lf=out["local_features"].float().clone(), targets=out["targets"].float().clone(),
+                         grads={k: p.grad.double().clone() for k, p in m.named_parameters() if p.grad is not None})
+    eng.fp8 = False
+    # bf16 path vs the oracle at 400 tokens on the base model
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(BASE))
+    lr_ = float(ref["loss"].detach())
+    assert abs(res["bf16"]["loss"] - lr_) < 1e-3 * abs(lr_), (res["bf16"]["loss"], lr_)
+    assert rel(res["bf16"]["targets"], ref["targets"].float()) < 1e-2
+    # fp8 vs bf16
+    b, f = res["bf16"], res["fp8"]
+    assert torch.equal(b["lf"], f["lf"])                                   # the conv front-end is not quantised
+    dl = abs(f["loss"] - b["loss"]) / abs(b["loss"])
+    dt = rel(f["targets"], b["targets"])
+    num, den = {}, {}
+    for k in b["grads"]:
+        g = group_of(k)
+        num[g] = num.get(g, 0.0) + float((f["grads"][k] - b["grads"][k]).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b["grads"][k].pow(2).sum())
+    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    print(f"fp8 vs bf16 path, base model, 400 tokens: loss {f['loss']:.6f} vs {b['loss']:.6f} (rel {dl:.3e}); targets rel L2 {dt:.3e}; "
+          f"gradient groups rel L2 {errs}")
+    assert dl < 1e-2 and dt < 8e-2
+    for g, e in errs.items():
+        assert e < 0.15, (g, e)
+
+
 def test_mask_gather_bit_exact_and_shapes(golden_dir):
     m, P = build(SMALL)
     ctx, tgt, vis = masks(golden_dir, 3)

@@ -408,6 +408,69 @@ def test_attention_ragged_with_empty_sequence(ops):
     assert bool(torch.isfinite(dq.float()).all()) and float(ws[1].abs().max()) == 0.0 and float(ws[3].abs().max()) == 0.0
 
 
+# ------------------------------------------------------------------------------------------------------------ MX fp8
+def _dequant(q, scales, M, K, ld_scale):
+    """e4m3 bytes [M][K] + block scales [K/128][ld_scale] dwords -> fp32 [M][K]."""
+    x = q.view(torch.float8_e4m3fn).float()
+    sc = scales[:(K // 128) * ld_scale].view(K // 128, ld_scale)[:, :M]                       # [kt][row] dwords (int32)
+    b = torch.stack([(sc >> (8 * j)) & 0xFF for j in range(4)], dim=-1)                          # [kt][row][4]
+    e = b.permute(1, 0, 2).reshape(M, K // 32).float() - 127.0                                   # [row][block]
+    return x * torch.exp2(e).repeat_interleave(32, dim=1)
+
+
+@pytest.mark.parametrize("M,K", [(300, 256), (1000, 768), (64, 3072)])
+def test_quantize_mxfp8(ops, M, K):
+    """Block scale = ceil(log2(amax / 448)) per 32 consecutive elements, elements RNE to e4m3: checked against the same rule in
+    torch (bit-exact bytes and scales), and the relative error of the round trip (<= 2^-4 per element, ~3 % rms)."""
+    x = (rnd(M, K, seed=90) * torch.exp2(torch.randint(-6, 6, (M, K // 32), generator=torch.Generator().manual_seed(1)).float())
+         .repeat_interleave(32, dim=1).to(dev())).to(torch.bfloat16)
+    x[3, 64:96] = 0                                                                               # an all-zero block
+    q = torch.full((M, K), 0x7F, dtype=torch.uint8, device=dev())
+    sc = torch.zeros(ops.fp8_scale_dwords(M + 5, K), dtype=torch.int32, device=dev())
+    ops.quantize_mxfp8(x, q, sc, M=M, K=K, ldx=K, ldq=K, ld_scale=M + 5)
+    xf = x.float().view(M, K // 32, 32)
+    amax = xf.abs().amax(-1)
+    s = torch.where(amax > 0, torch.ceil(torch.log2(amax / 448.0)), torch.zeros_like(amax))
+    want_q = (xf * torch.exp2(-s)[..., None]).reshape(M, K).to(torch.float8_e4m3fn).view(torch.uint8)
+    got_s = _dequant(torch.full_like(q, 0x38), sc, M, K, M + 5)                                   # 0x38 = 1.0: the scale alone
+    assert torch.equal(got_s.view(M, K // 32, 32)[..., 0], torch.exp2(s))
+    assert torch.equal(q, want_q)
+    back = _dequant(q, sc, M, K, M + 5)
+    assert float((back - x.float()).abs().max() / x.float().abs().max()) < 0.07 and relerr(back, x.float()) < 4e-2
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 256, "bf16"), (1000, 768, 768, "bf16"), (513, 3072, 768, "gelu2"), (700, 384, 1536, "gelu"),
+                                       (4100, 2304, 768, "bf16")])
+def test_gemm_mxfp8(ops, M, N, K, epi):
+    """MX fp8 GEMM against fp32 torch math on the DEQUANTISED operands (the kernel's own inputs: errors are fp32 summation order +
+    the bf16 output rounding), and against the unquantised product (the format's error, ~4 % per operand element averaging down
+    over K)."""
+    x = rnd(M, K, dtype=torch.bfloat16, seed=91)
+    w = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=92)
+    bias = rnd(N, seed=93)
+    qx, qw = torch.empty(M, K, dtype=torch.uint8, device=dev()), torch.empty(N, K, dtype=torch.uint8, device=dev())
+    sx = torch.zeros(ops.fp8_scale_dwords(M, K), dtype=torch.int32, device=dev())
+    sw = torch.zeros(ops.fp8_scale_dwords(N, K), dtype=torch.int32, device=dev())
+    ops.quantize_mxfp8(x, qx, sx, M=M, K=K, ldx=K, ldq=K, ld_scale=M)
+    ops.quantize_mxfp8(w, qw, sw, M=N, K=K, ldx=K, ldq=K, ld_scale=N)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    e = {"bf16": ops.EPI_BF16, "gelu2": ops.EPI_BIAS_GELU2, "gelu": ops.EPI_BIAS_GELU}[epi]
+    ops.gemm_mxfp8(qx, qw, sx, sw, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ld_scale_a=M, ld_scale_b=N, epilogue=e, bias=bias,
+                   C2=C2 if epi == "gelu2" else None)
+    h = (_dequant(qx, sx, M, K, M) @ _dequant(qw, sw, N, K, N).t() + bias).to(torch.bfloat16).float()
+    exact = x.float() @ w.float().t() + bias
+    if epi == "bf16":
+        assert relerr(C.float(), h) < 3e-3
+        assert relerr(C.float(), exact) < 5e-2
+    elif epi == "gelu":
+        assert relerr(C.float(), F.gelu(h)) < 4e-3
+    else:
+        hp = h.clone().requires_grad_(True)
+        F.gelu(hp).sum().backward()
+        assert relerr(C2.float(), F.gelu(h)) < 4e-3 and relerr(C.float(), hp.grad) < 4e-3
+
+
 # ------------------------------------------------------------------------------------------------------------ conv0
 @pytest.mark.parametrize("N,C_in,L,C", [(2, 1, 32159, 512), (3, 1, 4000, 32), (2, 2, 4000, 64)])
 def test_conv0_fwd_bwd(ops, N, C_in, L, C):

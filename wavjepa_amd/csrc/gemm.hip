@@ -211,6 +211,9 @@ struct EpiArgs {
     int seg_rows, seg_valid;
     float alpha;
     const int32_t* rowmap;   // gather forms: storage row of logical row m (GATHER 1) / of logical k (GATHER 2)
+    const uint32_t* sa;      // MX fp8 path: E8M0 block scales of A, [K / 128][lds_a] dwords (byte b = k block 4 kt + b)
+    const uint32_t* sb;      //              ... and of B, [K / 128][lds_b]
+    long lds_a, lds_b;       //              rows (dwords) per K tile in those arrays
 };
 
 template <int N>
@@ -374,6 +377,186 @@ __device__ __forceinline__ void eight_phase_loop(f32x4 (&acc)[8][4], char* smem,
     if (wm == 0) __builtin_amdgcn_s_barrier();    // balance the stagger
 }
 
+// ---- MX fp8 form of the eight-phase loop (256 x 256 x 128 tile) --------------------------------------------------------------
+// Operands are OCP e4m3 bytes with one E8M0 scale per 32 consecutive k (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4: twice the
+// bf16 MFMA rate per byte of operand).  A K tile is 128 deep = the SAME 128-B LDS rows, swizzle, staging and phase structure as
+// the bf16 loop above; the two 16-B chunks a lane reads per fragment (chunk g and chunk 4 + g) are the two halves of the MX
+// operand (measured with tools/micro/mx_fp8_probe.hip: lane (i, g) supplies k = 16 g .. 16 g + 15 in registers 0-3 and
+// k = 64 + 16 g .. in registers 4-7, and the scale byte of k block g of row i).  One MFMA per 16 x 16 fragment and K tile.
+// Block scales: [K / 128][rows] dwords (byte b = block 4 kt + b), 1 KiB per operand and K tile, staged by LDS-DMA next to the
+// ring (every wave moves 128 B of each, so the counted waits stay uniform) one K tile ahead.
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// The builtin form of the scaled MFMA is allocated with a destination DISTINCT from its accumulator input (early-clobber), which
+// at 128 accumulator registers per lane spills ~150 of them to scratch (and every scratch access is a vmcnt(0) in the LDS-DMA
+// ring).  In hardware vdst == srcC is the ordinary accumulate form, so the instruction is written out with the two tied.
+// "s_nop 1": VALU-written scale registers feed the MFMA (hipcc pads nothing inside an asm statement).
+__device__ __forceinline__ void mx_mfma(f32x4& acc, const v8i32& a, const v8i32& b, int scale_a, int scale_b) {
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                 : "+v"(acc) : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
+}
+
+constexpr unsigned F8_SCALE_OFF = 131072u;   // LDS: [parity][A 1 KiB | B 1 KiB] after the two 64-KiB operand parities
+
+template <int PAR>
+__device__ __forceinline__ void ep8_tile(f32x4 (&acc)[8][4], char* smem, const char* __restrict__ A, const char* __restrict__ B,
+                                         const char* __restrict__ SA, const char* __restrict__ SB, unsigned (&oa)[4], unsigned (&ob)[4],
+                                         unsigned& osa, unsigned& osb, unsigned sa_step, unsigned sb_step, unsigned a_lo, unsigned b_lo,
+                                         int wave, int lane, bool more1, bool more2) {
+    constexpr unsigned BUF = 65536u, BOFF = 32768u;
+    char* cur = smem + PAR * BUF;
+    char* oth = smem + (PAR ^ 1) * BUF;
+    const unsigned a_hi = a_lo ^ 64u, b_hi = b_lo ^ 64u;
+    const int i = lane & 15, g = lane >> 4, wm = wave >> 2, wn = wave & 3;
+    const char* sc = smem + F8_SCALE_OFF + PAR * 2048;          // this tile's scales
+    char* sc_o = smem + F8_SCALE_OFF + (PAR ^ 1) * 2048;        // next tile's
+    v8i32 af[4], b0f[2], b1f[2];             // one MX operand = chunk g (k 16 g ..) | chunk 4 + g (k 64 + 16 g ..) of a 128-B row
+    int sa[4], sb0[2], sb1[2];
+    auto lds8 = [&](unsigned lo, unsigned hi) {
+        const v4i32 x = *reinterpret_cast<const v4i32*>(cur + lo), y = *reinterpret_cast<const v4i32*>(cur + hi);
+        return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto scale = [&](const char* base, int row) { return (int)(*reinterpret_cast<const uint32_t*>(base + row * 4) >> (8 * g)); };
+    // LDS-DMA source = uniform matrix base + 32-bit per-lane offset (one register per stream instead of a 64-bit pointer)
+    auto dma = [&](const char* base, unsigned& off, char* dst) {
+        __builtin_amdgcn_global_load_lds((gl_void*)(base + off), (lds_void*)dst, 16, 0, 0);
+        off += 128;
+    };
+    // ---- phase 0: A rows 0-63, B cols 0-31
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { b0f[x] = lds8(b_lo + x * 2048, b_hi + x * 2048); sb0[x] = scale(sc + 1024, wn * 64 + x * 16 + i); }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { af[x] = lds8(a_lo + x * 2048, a_hi + x * 2048); sa[x] = scale(sc, wm * 128 + x * 16 + i); }
+    if (more1) { dma(A, oa[0], oth + (wave * 2) * 1024); dma(A, oa[1], oth + (wave * 2 + 1) * 1024); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            mx_mfma(acc[mi][ni], b0f[ni], af[mi], sb0[ni], sa[mi]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: B cols 32-63
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { b1f[x] = lds8(b_lo + 4096 + x * 2048, b_hi + 4096 + x * 2048); sb1[x] = scale(sc + 1024, wn * 64 + 32 + x * 16 + i); }
+    if (more1) {
+        dma(A, oa[2], oth + 16384 + (wave * 2) * 1024); dma(A, oa[3], oth + 16384 + (wave * 2 + 1) * 1024);
+        if (lane < 8) {                       // this wave's 128 B of the next tile's A / B block scales (rows 32 wave .. +31)
+            __builtin_amdgcn_global_load_lds((gl_void*)(SA + osa), (lds_void*)(sc_o + wave * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gl_void*)(SB + osb), (lds_void*)(sc_o + 1024 + wave * 128), 16, 0, 0);
+        }
+        osa += sa_step; osb += sb_step;
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            mx_mfma(acc[mi][2 + ni], b1f[ni], af[mi], sb1[ni], sa[mi]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: A rows 64-127
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { af[x] = lds8(a_lo + 8192 + x * 2048, a_hi + 8192 + x * 2048); sa[x] = scale(sc, wm * 128 + 64 + x * 16 + i); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            mx_mfma(acc[4 + mi][2 + ni], b1f[ni], af[mi], sb1[ni], sa[mi]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: B of tile t+2 into THIS parity (its B rows were last read two phases ago); the one counted wait
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+        dma(B, ob[0], cur + BOFF + (wave * 2) * 1024); dma(B, ob[1], cur + BOFF + (wave * 2 + 1) * 1024);
+        dma(B, ob[2], cur + BOFF + 16384 + (wave * 2) * 1024); dma(B, ob[3], cur + BOFF + 16384 + (wave * 2 + 1) * 1024);
+        wait_vmcnt<4>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            mx_mfma(acc[4 + mi][ni], b0f[ni], af[mi], sb0[ni], sa[mi]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+// A, B: e4m3 bytes, [M][K] / [N][K] (K contiguous, leading dimensions in BYTES, matrices < 4 GiB); K % 256 == 0
+__device__ __forceinline__ void eight_phase_loop_fp8(f32x4 (&acc)[8][4], char* smem, const char* __restrict__ A, const char* __restrict__ B,
+                                                     long lda, long ldb, int m0, int n0, int M, int N, int K, const EpiArgs& e, int wave,
+                                                     int lane) {
+    constexpr unsigned BUF = 65536u, BOFF = 32768u;
+    const int nkt = K / 128;
+    unsigned oa[4], ob[4];
+#pragma unroll
+    for (int hu = 0; hu < 4; ++hu) {
+        const int row = (hu >> 1) * 128 + wave * 16 + (hu & 1) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int ga = m0 + row, gb = n0 + row;
+        ga = ga < M ? ga : M - 1;
+        gb = gb < N ? gb : N - 1;
+        oa[hu] = (unsigned)((long)ga * lda + c * 16);
+        ob[hu] = (unsigned)((long)gb * ldb + c * 16);
+    }
+    // block scales: this wave's 32 rows of the tile, 4 rows (16 B) per lane of lanes 0-7; rows past the edge read the padding
+    const char* SA = reinterpret_cast<const char*>(e.sa);
+    const char* SB = reinterpret_cast<const char*>(e.sb);
+    unsigned osa = (unsigned)(m0 + wave * 32 + (lane & 7) * 4) * 4u, osb = (unsigned)(n0 + wave * 32 + (lane & 7) * 4) * 4u;
+    const unsigned sa_step = (unsigned)(e.lds_a * 4), sb_step = (unsigned)(e.lds_b * 4);
+    auto dma = [&](const char* base, unsigned& off, char* dst) {
+        __builtin_amdgcn_global_load_lds((gl_void*)(base + off), (lds_void*)dst, 16, 0, 0);
+        off += 128;
+    };
+    if (lane < 8) {
+        __builtin_amdgcn_global_load_lds((gl_void*)(SA + osa), (lds_void*)(smem + F8_SCALE_OFF + wave * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_void*)(SB + osb), (lds_void*)(smem + F8_SCALE_OFF + 1024 + wave * 128), 16, 0, 0);
+    }
+    osa += sa_step; osb += sb_step;
+#pragma unroll
+    for (int hu = 0; hu < 4; ++hu) dma(A, oa[hu], smem + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+#pragma unroll
+    for (int hu = 0; hu < 4; ++hu) dma(B, ob[hu], smem + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+    if (nkt > 1) {
+#pragma unroll
+        for (int hu = 0; hu < 4; ++hu) dma(B, ob[hu], smem + BUF + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+        wait_vmcnt<4>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const int i = lane & 15, g = lane >> 4, wm = wave >> 2, wn = wave & 3;
+    const unsigned sw = (unsigned)((g ^ ((i >> 1) & 7)) << 4);
+    const unsigned a_lo = (unsigned)((wm * 128 + i) * 128) + sw;
+    const unsigned b_lo = BOFF + (unsigned)((wn * 64 + i) * 128) + sw;
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nkt; t += 2) {
+        ep8_tile<0>(acc, smem, A, B, SA, SB, oa, ob, osa, osb, sa_step, sb_step, a_lo, b_lo, wave, lane, t + 1 < nkt, t + 2 < nkt);
+        ep8_tile<1>(acc, smem, A, B, SA, SB, oa, ob, osa, osb, sa_step, sb_step, a_lo, b_lo, wave, lane, t + 2 < nkt, t + 3 < nkt);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> compiler-scheduled readers (the epilogue)
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+}
+
 // GATHER 0: dense.  1: logical row m of A (row form) and of C lives at storage row rowmap[m] (conv dgrad over the active
 // rows).  2: logical k of A and B (both col form) lives at storage row rowmap[k] (conv wgrad over the active rows;
 // the list is padded with >= 256 readable entries).
@@ -385,7 +568,8 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     constexpr bool STAGGER = SCHED == 1;
     static_assert(SCHED == 0 || BN == 256, "the ping-pong / eight-phase schedules are built for the 8-wave 256x256 tile");
     static_assert(GATHER == 0 || SCHED == 0, "gather forms use the plain schedule");
-    static_assert(SCHED != 2 || (!AT && !BT), "eight-phase schedule: row-form operands");
+    static_assert(SCHED < 2 || (!AT && !BT), "eight-phase schedules: row-form operands");
+    static_assert(SCHED != 3 || EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2, "MX fp8 loop: forward epilogues");
     static_assert(GATHER != 1 || (!AT && EPI == WJ_EPI_BF16), "row gather: row-form A, bf16 output");
     static_assert(GATHER != 2 || (AT && BT && BN == 256), "k gather: col-form A and B, 256-wide tiles");
     constexpr int S = C_::STAGES, A_BYTES = C_::A_BYTES, STAGE_BYTES = C_::STAGE_BYTES, LPT = C_::LOADS_PER_TILE, MI = C_::MI;
@@ -449,7 +633,9 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
         }
     };
 
-    if constexpr (SCHED == 2) {
+    if constexpr (SCHED == 3) {
+        eight_phase_loop_fp8(acc, smem, reinterpret_cast<const char*>(A), reinterpret_cast<const char*>(B), lda, ldb, m0, n0, M, N, K, e, wave, lane);
+    } else if constexpr (SCHED == 2) {
         eight_phase_loop(acc, smem, A, B, lda, ldb, m0, n0, M, N, K, wave, lane);
     } else if (nkt > 0) {
 #pragma unroll
@@ -835,6 +1021,40 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
 }
 
 }  // namespace
+
+template <int EPI>
+int launch_fp8(const wj_gemm_fp8_args* a, hipStream_t s) {
+    const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + 255) / 256;
+    EpiArgs e;
+    e.C = a->C; e.C2 = a->epilogue == WJ_EPI_BIAS_GELU ? nullptr : a->C2; e.bias = a->bias; e.aux = nullptr; e.ldc = a->ldc; e.colsum = nullptr;
+    e.seg_rows = 1; e.seg_valid = 1; e.alpha = 1.f; e.rowmap = nullptr;
+    e.sa = (const uint32_t*)a->scale_a; e.sb = (const uint32_t*)a->scale_b; e.lds_a = a->ld_scale_a; e.lds_b = a->ld_scale_b;
+    auto kern = gemm3_kernel<false, false, EPI, 256, 3, 0>;
+    constexpr int lds = Cfg<256>::LDS_BYTES;     // 135168 >= ring (128 KiB) + two parities of block scales (4 KiB)
+    static_assert(lds >= 131072 + 4096, "LDS budget of the MX fp8 loop");
+    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return WJ_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(NT), lds, s, (const bf16_t*)a->A, (const bf16_t*)a->B, (long)a->lda, (long)a->ldb,
+                       a->M, a->N, a->K, tiles_n, 1, a->K, e);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_gemm_mxfp8(const wj_gemm_fp8_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
+    if (!a || !a->A || !a->B || !a->C || !a->scale_a || !a->scale_b) return WJ_ERR_ARG;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 256) || (a->N & 7) || (a->ldc & 7) || (a->lda & 15) || (a->ldb & 15)) return WJ_ERR_ARG;
+    if (a->ld_scale_a < a->M || a->ld_scale_b < a->N) return WJ_ERR_ARG;
+    if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->scale_a | (uintptr_t)a->scale_b) & 15) return WJ_ERR_ARG;
+    if (a->epilogue == WJ_EPI_BIAS_GELU2 && !a->C2) return WJ_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (a->epilogue) {
+        case WJ_EPI_BF16: return launch_fp8<WJ_EPI_BF16>(a, s);
+        case WJ_EPI_BIAS_GELU2:
+        case WJ_EPI_BIAS_GELU: return launch_fp8<WJ_EPI_BIAS_GELU2>(a, s);
+        default: return WJ_ERR_UNSUPPORTED;
+    }
+}
 
 extern "C" int wj_gemm_set_variant(int variant) {
     const int prev = g_forced_variant;

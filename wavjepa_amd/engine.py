@@ -249,6 +249,13 @@ class JepaEngine:
         # last predictor layer: after its attention only the target rows go on (WJ_TRIM_TAIL=0: every visible row)
         self.trim_tail = _os.environ.get("WJ_TRIM_TAIL", "1") != "0"
         self.tail = None
+        # MX fp8 forward GEMMs (BASELINE config 5; build-defined numerics, WJ_FP8=1 or engine.fp8 = True): every transformer forward
+        # linear whose K is a multiple of 256 runs on block-scaled e4m3 operands (wj_gemm_mxfp8, 2x the bf16 MFMA rate); weights are
+        # re-quantised from their bf16 shadows once per step, activations by wj_quantize_mxfp8 in front of each GEMM.  The backward
+        # is unchanged: it differentiates the bf16 graph (straight-through), with the saved bf16 activations and bf16 weights.
+        self.fp8 = _os.environ.get("WJ_FP8", "0") == "1"
+        self._w8: Dict[int, Tuple[torch.Tensor, torch.Tensor, int, int]] = {}     # bf16 weight pointer -> (q, scales, N, K)
+        self._a8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}               # per stack: activation scratch (q, scales)
         self.side = self._pick_side_stream() if self.use_side else torch.cuda.Stream(device=self.dev)
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
         self._bind_params()
@@ -328,6 +335,30 @@ class JepaEngine:
             return [(0, 0, self.N * self.S)]
         return [(c, c * self.N, self.N) for c in range(self.S)]
 
+    def _fp8_weights(self) -> None:
+        """(Re-)quantise the forward weights of the transformer stacks from their bf16 shadows (once per step in fp8 mode)."""
+        c = self.cfg
+        if not self._w8:
+            for layers, d in ((self.enc_layers, c.d_enc), (self.tea_layers, c.d_enc), (self.dec_layers, c.d_dec)):
+                for w in layers:
+                    for ptr, n, k in ((w.wqkv, 3 * d, d), (w.wo, d, d), (w.w1, 4 * d, d), (w.w2, d, 4 * d)):
+                        if k % 256 == 0:
+                            self._w8[ptr] = (_empty(n, k, dtype=torch.uint8, device=self.dev),
+                                             torch.zeros(ops.fp8_scale_dwords(n, k), dtype=torch.int32, device=self.dev), n, k)
+        for ptr, (q, sc, n, k) in self._w8.items():
+            ops.quantize_mxfp8(ptr, q, sc, M=n, K=k, ldx=k, ldq=k, ld_scale=n)
+
+    def _linear_fwd(self, stack: str, x, w_ptr: int, out, *, M: int, N: int, K: int, bias, epilogue: int = ops.EPI_BF16, C2=None) -> None:
+        """out[M, N] = x[M, K] . W^T (+ bias, epilogue): the bf16 GEMM, or in fp8 mode (eligible K) quantise x and run the MX fp8 GEMM."""
+        w8 = self._w8.get(w_ptr) if self.fp8 else None
+        if w8 is None:
+            ops.gemm(x, w_ptr, out, C2=C2, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=epilogue)
+            return
+        q, sc = self._a8[stack]
+        ops.quantize_mxfp8(x, q, sc, M=M, K=K, ldx=K, ldq=K, ld_scale=M)
+        ops.gemm_mxfp8(q, w8[0], sc, w8[1], out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ld_scale_a=M, ld_scale_b=N, epilogue=epilogue,
+                       C2=C2, bias=bias)
+
     def prepare_weights(self, force_cast: bool = False) -> None:
         """bf16 shadow copies (when stale) + the GEMM layouts of conv layers 1.. from the fp32 masters."""
         f = self.flat
@@ -335,6 +366,8 @@ class JepaEngine:
             ops.cast_f32_to_bf16(f.p32, f.p16, f.n)
             ops.cast_f32_to_bf16(f.t32, f.t16, f.tn)
             f.bf16_fresh = True
+        if self.fp8:
+            self._fp8_weights()
         C = self.C
         for si, pre in enumerate(self.stacks):
             for l, (_, k, s) in enumerate(self.cfg.conv_spec):
@@ -416,6 +449,12 @@ class JepaEngine:
         self.map_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         self.lf = _empty(M, c.d_enc, dtype=f32, device=dev)
         self.lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
+        # fp8 mode: one activation scratch (e4m3 bytes + block scales) per stack (the teacher runs beside the student)
+        self._a8 = {}
+        for tag, (m, d) in dict(tea=(M, c.d_enc), enc=(M, c.d_enc), dec=(Mp if train else 0, c.d_dec)).items():
+            if m > 0:
+                self._a8[tag] = (_empty(m, 4 * d, dtype=torch.uint8, device=dev),
+                                 torch.zeros(ops.fp8_scale_dwords(m, 4 * d), dtype=torch.int32, device=dev))
         # scratch stack (teacher / inference): one layer's worth, reused
         self.scratch = self._alloc_stack(M, c.d_enc, c.h_enc, N, 1)[0]
         self.enc_out = _empty(M, c.d_enc, dtype=f32, device=dev)
@@ -473,14 +512,14 @@ class JepaEngine:
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
                    mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None, save: bool = True,
                    x2_out: Optional[torch.Tensor] = None, x2_stats: Optional[torch.Tensor] = None,
-                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> None:
+                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, stack: str = "enc") -> None:
         """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1)))).
         `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask.
         save=False (teacher / inference): nothing is kept for a backward (no gelu' output, no softmax statistics).
         sub = (rows int32 [Ms], inverse int32 [M], Ms): only these rows continue after the attention (the last predictor layer:
         context rows are keys / values there and nothing reads their outputs)."""
         eps = self.cfg.ln_eps
-        ops.gemm(xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, lda=D, ldb=D, ldc=3 * D, bias=w.bqkv)
+        self._linear_fwd(stack, xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, bias=w.bqkv)
         if seq is not None:
             ops.attn_fwd(a.qkv, a.o, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], lse=a.lse if save else None)
         else:
@@ -491,13 +530,13 @@ class JepaEngine:
             ops.mask_gather_rows(a.o, rows, self.tail_o, n_rows=M, D=D, elem_bytes=2)
             ops.mask_gather_rows(x_in, rows, self.tail_x, n_rows=M, D=D, elem_bytes=4)
             o_in, x_in = self.tail_o, self.tail_x
-        ops.gemm(o_in, w.wo, a.p, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, bias=w.bo)
+        self._linear_fwd(stack, o_in, w.wo, a.p, M=M, N=D, K=D, bias=w.bo)
         ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1)
         if save:
-            ops.gemm(a.x1b, w.w1, a.h, C2=a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2)
+            self._linear_fwd(stack, a.x1b, w.w1, a.h, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2, C2=a.g)
         else:
-            ops.gemm(a.x1b, w.w1, a.g, M=M, N=4 * D, K=D, lda=D, ldb=D, ldc=4 * D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU)
-        ops.gemm(a.g, w.w2, a.f, M=M, N=D, K=4 * D, lda=4 * D, ldb=4 * D, ldc=D, bias=w.b2)
+            self._linear_fwd(stack, a.x1b, w.w1, a.g, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU)
+        self._linear_fwd(stack, a.g, w.w2, a.f, M=M, N=D, K=4 * D, bias=w.b2)
         # x2_out / x2_stats (teacher): the layer output goes to its own buffer and its per-clip (sum, sum of squares) is
         # accumulated on the way, so that the targets are ONE pass over the kept layers (wj_instnorm_mean)
         ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2 if x2_out is None else x2_out, y_bf16=a.x2b,
@@ -666,7 +705,7 @@ class JepaEngine:
         Mo = Md                          # rows that leave the predictor
         for i, (w, a) in enumerate(zip(self.dec_layers, self.dec_acts)):
             last = i == c.l_dec - 1
-            self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq, sub=self.tail if last else None)
+            self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq, sub=self.tail if last else None, stack="dec")
             x, xb = a.x2, a.x2b
         if self.tail is not None:
             Mo = plan.n_tgt
@@ -711,10 +750,11 @@ class JepaEngine:
         for i, w in enumerate(self.tea_layers):
             keep = c.l_enc - i <= c.top_k
             if keep and fused:
-                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, x2_out=self.tea_keep[kept], x2_stats=self.tea_stats[kept])
+                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, x2_out=self.tea_keep[kept], x2_stats=self.tea_stats[kept],
+                                stack="tea")
                 x, xb = self.tea_keep[kept], a.x2b
             else:
-                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False)
+                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, stack="tea")
                 # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
                 # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
                 x, xb = a.x2, a.x2b

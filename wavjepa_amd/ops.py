@@ -84,6 +84,24 @@ def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, 
          seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
 
 
+def gemm_mxfp8(A8: Ptr, B8: Ptr, scale_a: Ptr, scale_b: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
+               ld_scale_a: int, ld_scale_b: int, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None,
+               stream: Optional[int] = None) -> None:
+    """C = A . B^T on block-scaled e4m3 operands (see include/wavjepa_hip.h: wj_gemm_mxfp8)."""
+    _run("wj_gemm_mxfp8", "wj_gemm_fp8_args", stream, A=_p(A8), B=_p(B8), scale_a=_p(scale_a), scale_b=_p(scale_b), C=_p(C), C2=_p(C2),
+         bias=_p(bias), lda=lda, ldb=ldb, ldc=ldc, ld_scale_a=ld_scale_a, ld_scale_b=ld_scale_b, M=M, N=N, K=K, epilogue=epilogue)
+
+
+def quantize_mxfp8(x: Ptr, q: Ptr, scales: Ptr, *, M: int, K: int, ldx: int, ldq: int, ld_scale: int, stream: Optional[int] = None) -> None:
+    """bf16 [M][ldx] -> e4m3 bytes [M][ldq] + E8M0 block scales [K / 128][ld_scale] dwords."""
+    _run("wj_quantize_mxfp8", "wj_quantize_fp8_args", stream, x=_p(x), q=_p(q), scales=_p(scales), ldx=ldx, ldq=ldq, ld_scale=ld_scale, M=M, K=K)
+
+
+def fp8_scale_dwords(rows: int, K: int) -> int:
+    """Dwords of a block-scale array for `rows` rows and K columns, including the 256 dwords of readable padding the GEMM asks for."""
+    return (K // 128) * rows + 256
+
+
 def gemm_set_variant(variant: int) -> int:
     """Force the GEMM tile/schedule variant (A/B runs); -1 = automatic.  Returns the previous setting."""
     return int(_abi.load().wj_gemm_set_variant(int(variant)))
