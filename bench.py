@@ -64,9 +64,11 @@ def gemm_kernel_name(f) -> str:
 
 
 def pmc_traffic_for(name: str):
-    """HBM bytes per launch of a GEMM class from the committed PMC summary (profiles/r01_pmc_traffic.json, collected with
+    """HBM bytes per launch of a GEMM class from the committed PMC summary (profiles/r02_pmc_traffic.json, collected with
     tools/pmc_traffic.py on this same command): launch-weighted mean over the tile variants of the class, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     m = __import__("re").match(r"gemm_kernel<([NT])([NT]),(\w+)>", name)
     if not m or not os.path.exists(path):
         return None
