@@ -29,7 +29,7 @@ def small_model(**kw):
 def test_abi_library_exports_every_declared_symbol():
     from wavjepa_amd import _abi
     lib = _abi.load()
-    assert lib.wj_abi_version() == _abi.DEFINES["WJ_ABI_VERSION"] == 5
+    assert lib.wj_abi_version() == _abi.DEFINES["WJ_ABI_VERSION"]
     assert len(_abi.FUNCTIONS) >= 25
     for fn in _abi.FUNCTIONS:
         assert hasattr(lib, fn), fn
