@@ -98,7 +98,9 @@ def profile_one_step(runner, source, step_idx: int):
     classes, shapes = {}, {}
     for fn, f, e0, e1 in recs:
         ms = e0.elapsed_time(e1)
-        if fn == "wj_gemm_mxfp8":
+        if fn == "wj_wgrad_grouped":
+            name, flops, nbytes = "wgrad_grouped<TT,ATOMIC_F32>", f["flops"], f["bytes"]
+        elif fn == "wj_gemm_mxfp8":
             name, flops = f"gemm_mxfp8<NN,{ {0: 'BF16', 1: 'BIAS_GELU2', 6: 'BIAS_GELU'}[f['epilogue']] }>", 2.0 * f["M"] * f["N"] * f["K"]
             nbytes = 1.03 * f["K"] * (f["M"] + f["N"]) + 2.0 * f["M"] * f["N"] * (2 if f["epilogue"] == 1 else 1)
             key = f"{name} M={f['M']} N={f['N']} K={f['K']}"

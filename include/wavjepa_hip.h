@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 5
+#define WJ_ABI_VERSION 6
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -101,6 +101,20 @@ typedef struct {
     int32_t M, K;
 } wj_quantize_fp8_args;
 int wj_quantize_mxfp8(const wj_quantize_fp8_args*, void* stream);
+
+/* Grouped weight gradients: for x < n (n <= 8):  C_x[M_x][N_x] (f32) += A_x^T . B_x  with A_x stored [K_x][M_x] (= dY, token-major)
+ * and B_x stored [K_x][N_x] (= X, token-major) -- the autograd wgrad of nn.Linear, dW = dY^T X -- in ONE launch with ONE split-K
+ * factor chosen for the group (atomic accumulation like WJ_EPI_ATOMIC_F32).  The four wgrads of a transformer layer together fill
+ * the chip at a 3-8x smaller split than each alone: 3-4x fewer float-atomic bytes (csrc/gemm.hip).  M, N, lda, ldb % 8 == 0. */
+typedef struct {
+    const void* A[8];
+    const void* B[8];
+    void* C[8];
+    int64_t lda[8], ldb[8], ldc[8];
+    int32_t M[8], N[8], K[8];
+    int32_t n;
+} wj_wgrad_group_args;
+int wj_wgrad_grouped(const wj_wgrad_group_args*, void* stream);
 
 /* Tuning / A-B hook (tools/gemm_bench.py, tests): force the tile/schedule variant of wj_gemm_bf16 (0..3, see csrc/gemm.hip;
  * a variant that cannot run a shape falls back to variant 0); -1 = automatic selection.  Returns the previous setting.

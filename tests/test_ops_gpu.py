@@ -120,6 +120,23 @@ def test_gemm_wgrad_layout(ops, Mtok, Nout, Kin, split):
     assert relerr(dW, ref) < 1e-3
 
 
+@pytest.mark.parametrize("dims,K", [([(384, 128), (128, 128), (512, 128), (128, 512)], 1000), ([(192, 64), (64, 64), (256, 64), (64, 256)] * 2, 777),
+                                    ([(2304, 768), (768, 768)], 2500)])
+def test_wgrad_grouped(ops, dims, K):
+    """Several dW = dY^T X problems in one launch (one split-K factor for the group) == the individual fp32 products, accumulated
+    on top of what the gradient buffers already hold."""
+    probs, refs = [], []
+    for i, (n_out, k_in) in enumerate(dims):
+        dy = rnd(K, n_out, dtype=torch.bfloat16, seed=300 + i)
+        x = rnd(K, k_in, dtype=torch.bfloat16, seed=400 + i)
+        gw = rnd(n_out, k_in, seed=500 + i)
+        refs.append(gw.clone() + dy.float().t() @ x.float())
+        probs.append((dy, x, gw, n_out, k_in, K))
+    ops.wgrad_grouped(probs)
+    for (dy, x, gw, *_), ref in zip(probs, refs):
+        assert relerr(gw, ref) < 2e-5
+
+
 def test_gemm_gather_forms(ops):
     """Sparse conv backward GEMMs: logical rows / logical k taken from a row list == the dense GEMM on compacted copies."""
     g = torch.Generator().manual_seed(20)

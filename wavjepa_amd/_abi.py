@@ -31,6 +31,7 @@ def _strip_comments(text: str) -> str:
 def parse_header(path: str = HEADER) -> Tuple[Dict[str, List[Tuple[str, object]]], List[str], Dict[str, int]]:
     """Returns ({struct name: [(field, ctype)]}, [function names], {enum constant: value})."""
     text = _strip_comments(open(path).read())
+    defines = {k: int(v, 0) for k, v in re.findall(r"^\s*#\s*define\s+(WJ_\w+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\s*$", text, flags=re.M)}
     structs: Dict[str, List[Tuple[str, object]]] = {}
     for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
         fields: List[Tuple[str, object]] = []
@@ -47,7 +48,12 @@ def parse_header(path: str = HEADER) -> Tuple[Dict[str, List[Tuple[str, object]]
                 n = n.strip()
                 if not n:
                     continue
-                fields.append((n, ctypes.c_void_p if is_ptr else _SCALARS[base]))
+                ctype = ctypes.c_void_p if is_ptr else _SCALARS[base]
+                arr = re.match(r"(\w+)\[(\w+)\]$", n)          # fixed-size array member: name[N] (N a number or a #define)
+                if arr:
+                    n, dim = arr.group(1), arr.group(2)
+                    ctype = ctype * (int(dim) if dim.isdigit() else defines[dim])
+                fields.append((n, ctype))
         structs[name] = fields
     funcs = re.findall(r"\bint\s+(wj_\w+)\s*\(", text)
     enums: Dict[str, int] = {}

@@ -560,10 +560,11 @@ __device__ __forceinline__ void eight_phase_loop_fp8(f32x4 (&acc)[8][4], char* s
 // GATHER 0: dense.  1: logical row m of A (row form) and of C lives at storage row rowmap[m] (conv dgrad over the active
 // rows).  2: logical k of A and B (both col form) lives at storage row rowmap[k] (conv wgrad over the active rows;
 // the list is padded with >= 256 readable entries).
+// The body of one workgroup: `bid` of `nwg` workgroups of ONE problem (the plain kernel passes blockIdx / gridDim; the grouped
+// kernel below passes the workgroup's position inside its problem of the group).
 template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
-__global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                                      long lda, long ldb, int M, int N, int K, int tiles_n,
-                                                                      int split_k, int k_per_split, EpiArgs e) {
+__device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, long lda, long ldb, int M, int N,
+                                           int K, int tiles_n, int split_k, int k_per_split, const EpiArgs& e, int bid, int nwg) {
     using C_ = Cfg<BN>;
     constexpr bool STAGGER = SCHED == 1;
     static_assert(SCHED == 0 || BN == 256, "the ping-pong / eight-phase schedules are built for the 8-wave 256x256 tile");
@@ -579,10 +580,10 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
     const int wm = wave / C_::WAVES_N, wn = wave % C_::WAVES_N;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = xcd_remap(bid, nwg);
     // split-K work order: K-slice major, tile minor -> the tiles that stream the same K-slice of A / B are neighbours on one
     // XCD and share it through L2 (tile-major order fetched ~3x the algorithmic bytes: profiles/r01_pmc_traffic.json)
-    const int ntiles = gridDim.x / split_k;
+    const int ntiles = nwg / split_k;
     const int ksl = wg / ntiles, tile = wg - ksl * ntiles;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -949,6 +950,47 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
 }
 
 template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
+__global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                      long lda, long ldb, int M, int N, int K, int tiles_n,
+                                                                      int split_k, int k_per_split, EpiArgs e) {
+    gemm3_body<AT, BT, EPI, BN, SCHED, GATHER>(A, B, lda, ldb, M, N, K, tiles_n, split_k, k_per_split, e, blockIdx.x, gridDim.x);
+}
+
+// ---- grouped split-K weight gradients -----------------------------------------------------------------------------------------
+// Several C_p[M_p, N_p] += A_p^T B_p problems (both operands token-major: the wgrads of one transformer layer, or of two) in ONE
+// launch.  Why: a lone wgrad has few output tiles (9-36), so filling 256 CUs needs split-K 7-28, and every K slice ends with a
+// 256 x 256 fp32 atomic tile -- at the chip-wide float-atomic rate (~1.3 TB/s) that epilogue was 35-50 % of each launch.  Grouped,
+// the tiles of all problems fill the chip with split-K 1-8: 3-4x fewer atomic bytes, K loops 3-8x longer.
+// Workgroup ranges of the problems are padded to multiples of 8 so that blockIdx % 8 still names the XCD inside a problem.
+struct GroupProblem {
+    const bf16_t* A;
+    const bf16_t* B;
+    float* C;
+    long lda, ldb, ldc;
+    int M, N, K, tiles_n, split, kps, wg_begin, nwg;
+};
+constexpr int GROUP_MAX = 8;
+struct GroupTable {
+    GroupProblem p[GROUP_MAX];
+    int n;
+};
+
+template <int BN>
+__global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_grouped_wgrad_kernel(GroupTable g) {
+    int q = 0;
+#pragma unroll 1
+    for (int x = 1; x < g.n; ++x)
+        if ((int)blockIdx.x >= g.p[x].wg_begin) q = x;
+    const GroupProblem& P = g.p[q];
+    const int bid = blockIdx.x - P.wg_begin;
+    if (bid >= P.nwg) return;               // padding workgroup
+    EpiArgs e;
+    e.C = P.C; e.C2 = nullptr; e.bias = nullptr; e.aux = nullptr; e.colsum = nullptr; e.ldc = P.ldc; e.seg_rows = 1; e.seg_valid = 1;
+    e.alpha = 1.f; e.rowmap = nullptr; e.sa = nullptr; e.sb = nullptr; e.lds_a = 0; e.lds_b = 0;
+    gemm3_body<true, true, WJ_EPI_ATOMIC_F32, BN, 0, 0>(P.A, P.B, P.lda, P.ldb, P.M, P.N, P.K, P.tiles_n, P.split, P.kps, e, bid, P.nwg);
+}
+
+template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
 int launch(const wj_gemm_args* a, hipStream_t s) {
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     int split = a->split_k < 1 ? 1 : a->split_k;
@@ -1054,6 +1096,55 @@ extern "C" int wj_gemm_mxfp8(const wj_gemm_fp8_args* a, void* stream) {
         case WJ_EPI_BIAS_GELU: return launch_fp8<WJ_EPI_BIAS_GELU2>(a, s);
         default: return WJ_ERR_UNSUPPORTED;
     }
+}
+
+template <int BN>
+int launch_grouped(const wj_wgrad_group_args* a, hipStream_t s) {
+    GroupTable g;
+    g.n = a->n;
+    long tiles_total = 0;
+    for (int x = 0; x < a->n; ++x)
+        tiles_total += (long)((a->M[x] + BM - 1) / BM) * ((a->N[x] + BN - 1) / BN);
+    const int slots = BN == 256 ? 256 : 512;                         // co-resident workgroups of this tile variant
+    int begin = 0;
+    for (int x = 0; x < a->n; ++x) {
+        GroupProblem& P = g.p[x];
+        P.A = (const bf16_t*)a->A[x]; P.B = (const bf16_t*)a->B[x]; P.C = (float*)a->C[x];
+        P.lda = a->lda[x]; P.ldb = a->ldb[x]; P.ldc = a->ldc[x]; P.M = a->M[x]; P.N = a->N[x]; P.K = a->K[x];
+        const int tiles_m = (P.M + BM - 1) / BM;
+        P.tiles_n = (P.N + BN - 1) / BN;
+        const int tiles = tiles_m * P.tiles_n;
+        // one split factor for the whole group: the group's tiles x split ~ the chip (rounded to nearest), K slices >= 1024 deep
+        int split = (int)((slots + tiles_total / 2) / tiles_total);
+        if (split < 1) split = 1;
+        const int maxs = (P.K + 1023) / 1024;
+        if (split > maxs) split = maxs;
+        P.kps = ((P.K + split - 1) / split + 63) / 64 * 64;
+        P.split = (P.K + P.kps - 1) / P.kps;
+        P.nwg = tiles * P.split;
+        P.wg_begin = begin;
+        begin += (P.nwg + 7) / 8 * 8;
+    }
+    auto kern = gemm3_grouped_wgrad_kernel<BN>;
+    constexpr int lds = Cfg<BN>::LDS_BYTES;
+    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return WJ_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(begin), dim3(NT), lds, s, g);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_wgrad_grouped(const wj_wgrad_group_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
+    if (!a || a->n < 1 || a->n > GROUP_MAX) return WJ_ERR_ARG;
+    bool wide = true;
+    for (int x = 0; x < a->n; ++x) {
+        if (!a->A[x] || !a->B[x] || !a->C[x] || a->M[x] <= 0 || a->N[x] <= 0 || a->K[x] <= 0) return WJ_ERR_ARG;
+        if ((a->M[x] & 7) || (a->N[x] & 7) || (a->lda[x] & 7) || (a->ldb[x] & 7) || (a->ldc[x] & 3)) return WJ_ERR_ARG;
+        if (((uintptr_t)a->A[x] | (uintptr_t)a->B[x] | (uintptr_t)a->C[x]) & 15) return WJ_ERR_ARG;
+        wide = wide && a->N[x] % 256 == 0;
+    }
+    return wide ? launch_grouped<256>(a, (hipStream_t)stream) : launch_grouped<128>(a, (hipStream_t)stream);
 }
 
 extern "C" int wj_gemm_set_variant(int variant) {

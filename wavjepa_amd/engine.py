@@ -487,16 +487,18 @@ class JepaEngine:
         self.mse_ws = _empty(ops.workspace_bytes("wj_masked_mse", B=N, G=G, T=T) // 4, dtype=f32, device=dev)
         # backward scratch, one set per stack width
         self.bw = {}
-        for tag, (m, d) in dict(enc=(M, c.d_enc), dec=(Mp, c.d_dec)).items():
-            # buffers read by the side-stream wgrad GEMMs exist twice (layer parity), so the main chain may run one layer ahead
+        for tag, (m, d, nbuf, group) in dict(enc=(M, c.d_enc, 4, 2), dec=(Mp, c.d_dec, 2, 1)).items():
+            # The weight gradients of `group` consecutive layers go out as ONE grouped launch on the side stream (wj_wgrad_grouped:
+            # one small split-K factor for 4-8 problems instead of a large one per problem).  The buffers it reads (dY of every
+            # linear) therefore exist 2 * group times (slot = layer % nbuf), so that the main chain may run a whole group ahead.
             self.bw[tag] = dict(
                 dy=_empty(m, d, dtype=f32, device=dev), ds=_empty(m, d, dtype=f32, device=dev),
                 dx1=_empty(m, d, dtype=f32, device=dev), do=_empty(m, d, dtype=bf, device=dev),
-                dsb2=[_empty(m, d, dtype=bf, device=dev) for _ in range(2)],
-                dsb1=[_empty(m, d, dtype=bf, device=dev) for _ in range(2)],
-                dh=[_empty(m, 4 * d, dtype=bf, device=dev) for _ in range(2)],
-                dqkv=[_empty(m, 3 * d, dtype=bf, device=dev) for _ in range(2)],
-                done=[torch.cuda.Event() for _ in range(2)], used=[False, False])
+                dsb2=[_empty(m, d, dtype=bf, device=dev) for _ in range(nbuf)],
+                dsb1=[_empty(m, d, dtype=bf, device=dev) for _ in range(nbuf)],
+                dh=[_empty(m, 4 * d, dtype=bf, device=dev) for _ in range(nbuf)],
+                dqkv=[_empty(m, 3 * d, dtype=bf, device=dev) for _ in range(nbuf)],
+                done=[torch.cuda.Event() for _ in range(nbuf)], used=[False] * nbuf, nbuf=nbuf, group=group, pending=[], pending_slots=[])
         # scratch for two-stage parameter-gradient reductions (LayerNorm: [1536][3][D]; attention in_proj bias: [B][3D])
         red_bytes = max(ops.workspace_bytes("wj_layernorm_bwd", D=max(c.d_enc, c.d_dec, C)),
                         ops.workspace_bytes("wj_attn_bwd", B=N * G, H=c.h_dec, hd=c.d_dec // c.h_dec),
@@ -568,10 +570,12 @@ class JepaEngine:
     def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dx_out: torch.Tensor,
                    M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int,
                    seq: Optional[Tuple[torch.Tensor, int]] = None,
-                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None) -> None:
+                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, flush: bool = True) -> bool:
         """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer.
-        The four weight-gradient GEMMs only need (dY, X) and nothing downstream needs them before the optimiser: they run on
-        the side stream while the main stream continues the dgrad chain."""
+        The four weight-gradient GEMMs only need (dY, X) and nothing downstream needs them before the optimiser: they are queued
+        and go out as one grouped launch on the side stream (with `flush`; `parity` = this layer's buffer slot) while the main
+        stream continues the dgrad chain.  Returns True when the queue was flushed (the queued layers' gradients are then final in
+        side-stream order)."""
         ds, dx1, do = bw["ds"], bw["dx1"], bw["do"]
         dsb2, dsb1, dh, dqkv = bw["dsb2"][parity], bw["dsb1"][parity], bw["dh"][parity], bw["dqkv"][parity]
         if self.use_side and bw["used"][parity]:
@@ -585,10 +589,7 @@ class JepaEngine:
         ops.gemm(dsb2, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
                  colsum=w.gb1)           # linear1.bias gradient = column sums of dh, fused into the producing epilogue
 
-        def wgrad_mlp():
-            self._wgrad(dsb2, a.g, w.gw2, D, 4 * D, M)
-            self._wgrad(dh, a.x1b, w.gw1, 4 * D, D, M)
-        self._on_side(wgrad_mlp)
+        bw["pending"] += [(dsb2, a.g, w.gw2, D, 4 * D, M), (dh, a.x1b, w.gw1, 4 * D, D, M)]
         ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
         ops.layernorm_bwd(dx1, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb1, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
                           workspace=self.red_ws)
@@ -605,14 +606,22 @@ class JepaEngine:
         else:
             ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
 
-        def wgrad_attn():
-            self._wgrad(dsb1, o_in, w.gwo, D, D, M)
-            self._wgrad(dqkv, xb_in, w.gwqkv, 3 * D, D, Mall)
-            if self.use_side:
-                bw["done"][parity].record(self.side)
-                bw["used"][parity] = True
-        self._on_side(wgrad_attn)
+        bw["pending"] += [(dsb1, o_in, w.gwo, D, D, M), (dqkv, xb_in, w.gwqkv, 3 * D, D, Mall)]
+        bw["pending_slots"].append(parity)
+        if flush:
+            probs, slots = bw["pending"], bw["pending_slots"]
+            bw["pending"], bw["pending_slots"] = [], []
+
+            def wgrads():
+                for i in range(0, len(probs), 8):
+                    ops.wgrad_grouped(probs[i:i + 8])
+                if self.use_side:
+                    for sl in slots:
+                        bw["done"][sl].record(self.side)
+                        bw["used"][sl] = True
+            self._on_side(wgrads)
         ops.gemm(dqkv, w.wqkv, dx_out, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds_all)
+        return flush
 
     # ------------------------------------------------------------------------------------------------ front-end
     def _frontend(self, audio: torch.Tensor) -> None:
@@ -802,7 +811,7 @@ class JepaEngine:
         dy = bw["dy"]
         for i in range(c.l_dec - 1, -1, -1):
             x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
-            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Md, Dd, c.h_dec, N * G, plan.vis_u8, bw, i & 1, dseq,
+            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Md, Dd, c.h_dec, N * G, plan.vis_u8, bw, i % bw["nbuf"], dseq,
                             sub=self.tail if (rag and i == c.l_dec - 1) else None)
         n_ctx = plan.n_ctx
         ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
@@ -822,11 +831,19 @@ class JepaEngine:
         ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("encoder.norm.weight"), self.enc_fm, self.enc_fr, M=Me, D=De, ds_f32=bw["dy"],
                           dgamma=f.gptr("encoder.norm.weight"), dbeta=f.gptr("encoder.norm.bias"), workspace=self.red_ws)
         dy = bw["dy"]
+        enc_ready = set()
         for i in range(c.l_enc - 1, -1, -1):
             first = (self.enc_in, self.enc_in_b) if rag else (self.lf, self.lf_b)
             x_in, xb_in = first if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
-            self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, Me, De, c.h_enc, N, plan.ctx_u8, bw, i & 1, eseq)
-            ready(f"enc:{i}")
+            # the weight gradients of two layers share a grouped launch: a layer's section of the gradient buffer is final (and its
+            # all-reduce bucket may go) once the launch that carries it has been queued
+            done = self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, Me, De, c.h_enc, N, plan.ctx_u8, bw, i % bw["nbuf"],
+                                   eseq, flush=(c.l_enc - 1 - i) % bw["group"] == bw["group"] - 1 or i == 0)
+            if done:
+                for j in range(min(c.l_enc - 1, i + bw["group"] - 1), i - 1, -1):
+                    if j not in enc_ready:
+                        enc_ready.add(j)
+                        ready(f"enc:{j}")
         # dy = d(local_features) fp32 (zero on non-context rows).  The teacher branch is detached (jepa.py:408).
         if rag:
             ops.unmask_rows_f32(dy, plan.inv, self.d_lf_b, M=M, D=De, src_is_f32=True, dst_is_bf16=True)
@@ -914,7 +931,7 @@ class JepaEngine:
                 ops.zero_rows(self.dpost_ptr[0] + c0 * self.P[0] * C * 2, rows0, n_rows=n0, row_bytes=C * 2)
         self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
         for tag in ("enc", "dec"):
-            self.bw[tag]["used"] = [False, False]
+            self.bw[tag]["used"] = [False] * self.bw[tag]["nbuf"]
         if on_grads_ready is not None:
             on_grads_ready("front")
 

@@ -102,6 +102,26 @@ def fp8_scale_dwords(rows: int, K: int) -> int:
     return (K // 128) * rows + 256
 
 
+def wgrad_grouped(problems, stream: Optional[int] = None) -> None:
+    """problems: [(dY, X, gW, n_out, k_in, m_tok)] (<= 8): gW[n_out, k_in] += dY[m_tok, n_out]^T @ X[m_tok, k_in], one launch."""
+    a = STRUCTS["wj_wgrad_group_args"]()
+    for i, (dY, X, gW, n_out, k_in, m_tok) in enumerate(problems):
+        a.A[i], a.B[i], a.C[i] = _p(dY), _p(X), _p(gW)
+        a.lda[i], a.ldb[i], a.ldc[i] = n_out, k_in, k_in
+        a.M[i], a.N[i], a.K[i] = n_out, k_in, m_tok
+    a.n = len(problems)
+    if PROFILE is None:
+        _abi.call("wj_wgrad_grouped", a, _stream() if stream is None else stream)
+        return
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    _abi.call("wj_wgrad_grouped", a, s.cuda_stream)
+    e1.record(s)
+    PROFILE.append(("wj_wgrad_grouped", dict(flops=sum(2.0 * p[3] * p[4] * p[5] for p in problems), n=len(problems),
+                                             bytes=sum(2.0 * p[5] * (p[3] + p[4]) + 4.0 * p[3] * p[4] for p in problems)), e0, e1))
+
+
 def gemm_set_variant(variant: int) -> int:
     """Force the GEMM tile/schedule variant (A/B runs); -1 = automatic.  Returns the previous setting."""
     return int(_abi.load().wj_gemm_set_variant(int(variant)))
