@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 6
+#define WJ_ABI_VERSION 7
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -81,11 +81,13 @@ typedef struct {
     const void* B;
     const void* scale_a;
     const void* scale_b;
-    void* C;
+    void* C;            /* may be NULL for WJ_EPI_BIAS_GELU when q_out is given (the teacher keeps only the fp8 form of gelu(h)) */
     void* C2;
     const float* bias;
+    void* q_out;        /* optional, GELU epilogues (N % 128 == 0): gelu(h) also as MX fp8, e4m3 bytes [M][ldc] ...               */
+    void* q_scales;     /* ... + block scales [N / 128][ld_q_scale] dwords: the A operand of linear2 straight from linear1       */
     int64_t lda, ldb, ldc;
-    int64_t ld_scale_a, ld_scale_b;
+    int64_t ld_scale_a, ld_scale_b, ld_q_scale;
     int32_t M, N, K;
     int32_t epilogue;
 } wj_gemm_fp8_args;
@@ -147,6 +149,9 @@ typedef struct {
     float* mean;
     float* rstd;
     float* group_stats;
+    void* y_fp8;        /* optional (D % 128 == 0): y as MX fp8 -- e4m3 bytes [M][D] ...                                              */
+    void* y_fp8_scales; /* ... + E8M0 block scales [D / 128][ld_fp8_scale] dwords, exactly what wj_quantize_mxfp8 would produce   */
+    int64_t ld_fp8_scale; /*   from bf16(y): the next GEMM's A operand without a separate quantisation pass (config 5)             */
     int32_t M, D;
     int32_t x_is_bf16;
     int32_t in_seg, in_valid;

@@ -488,6 +488,43 @@ def test_gemm_mxfp8(ops, M, N, K, epi):
         assert relerr(C2.float(), F.gelu(h)) < 4e-3 and relerr(C.float(), hp.grad) < 4e-3
 
 
+def test_fp8_outputs_fused_into_layernorm_and_gelu_epilogue(ops):
+    """Config 5 producers: LayerNorm and the linear1 GELU epilogue emit their output directly in the MX fp8 operand format; both
+    must be BIT-identical to wj_quantize_mxfp8 applied to the bf16 output they also write (bytes and block scales)."""
+    M, D = 333, 768
+    x, r = rnd(M, D, seed=95) * 3 + 0.5, rnd(M, D, dtype=torch.bfloat16, seed=96)
+    g, b = 1 + 0.1 * rnd(D, seed=97), 0.1 * rnd(D, seed=98)
+    yb = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+    q = torch.zeros(M, D, dtype=torch.uint8, device=dev())
+    sc = torch.zeros(ops.fp8_scale_dwords(M, D), dtype=torch.int32, device=dev())
+    ops.layernorm_fwd(x, g, b, M=M, D=D, eps=1e-6, r=r, y_bf16=yb, y_fp8=q, y_fp8_scales=sc, ld_fp8_scale=M)
+    q2, sc2 = torch.zeros_like(q), torch.zeros_like(sc)
+    ops.quantize_mxfp8(yb, q2, sc2, M=M, K=D, ldx=D, ldq=D, ld_scale=M)
+    assert torch.equal(q, q2) and torch.equal(sc[:(D // 128) * M], sc2[:(D // 128) * M])
+    # GELU epilogue of the MX fp8 GEMM (teacher form: fp8 only; training form: bf16 gelu + gelu' + fp8)
+    M, N, K = 700, 1024, 768
+    a, w, bias = rnd(M, K, dtype=torch.bfloat16, seed=99), rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=100), rnd(N, seed=101)
+    qa, qw = torch.empty(M, K, dtype=torch.uint8, device=dev()), torch.empty(N, K, dtype=torch.uint8, device=dev())
+    sa = torch.zeros(ops.fp8_scale_dwords(M, K), dtype=torch.int32, device=dev())
+    sw = torch.zeros(ops.fp8_scale_dwords(N, K), dtype=torch.int32, device=dev())
+    ops.quantize_mxfp8(a, qa, sa, M=M, K=K, ldx=K, ldq=K, ld_scale=M)
+    ops.quantize_mxfp8(w, qw, sw, M=N, K=K, ldx=K, ldq=K, ld_scale=N)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ld_scale_a=M, ld_scale_b=N, bias=bias)
+    gl, gp = torch.empty(M, N, dtype=torch.bfloat16, device=dev()), torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    qg = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    sg = torch.zeros(ops.fp8_scale_dwords(M, N), dtype=torch.int32, device=dev())
+    ops.gemm_mxfp8(qa, qw, sa, sw, gp, C2=gl, epilogue=ops.EPI_BIAS_GELU2, q_out=qg, q_scales=sg, ld_q_scale=M, **kw)
+    qr, sr = torch.zeros_like(qg), torch.zeros_like(sg)
+    ops.quantize_mxfp8(gl, qr, sr, M=M, K=N, ldx=N, ldq=N, ld_scale=M)
+    assert torch.equal(qg, qr) and torch.equal(sg[:(N // 128) * M], sr[:(N // 128) * M])
+    gl2, gp2 = torch.empty_like(gl), torch.empty_like(gp)
+    ops.gemm_mxfp8(qa, qw, sa, sw, gp2, C2=gl2, epilogue=ops.EPI_BIAS_GELU2, **kw)
+    assert torch.equal(gl, gl2) and torch.equal(gp, gp2)                       # the bf16 outputs do not change
+    qt, st = torch.zeros_like(qg), torch.zeros_like(sg)
+    ops.gemm_mxfp8(qa, qw, sa, sw, None, epilogue=ops.EPI_BIAS_GELU, q_out=qt, q_scales=st, ld_q_scale=M, **kw)      # no bf16 output at all
+    assert torch.equal(qt, qg) and torch.equal(st[:(N // 128) * M], sg[:(N // 128) * M])
+
+
 # ------------------------------------------------------------------------------------------------------------ conv0
 @pytest.mark.parametrize("N,C_in,L,C", [(2, 1, 32159, 512), (3, 1, 4000, 32), (2, 2, 4000, 64)])
 def test_conv0_fwd_bwd(ops, N, C_in, L, C):

@@ -214,6 +214,9 @@ struct EpiArgs {
     const uint32_t* sa;      // MX fp8 path: E8M0 block scales of A, [K / 128][lds_a] dwords (byte b = k block 4 kt + b)
     const uint32_t* sb;      //              ... and of B, [K / 128][lds_b]
     long lds_a, lds_b;       //              rows (dwords) per K tile in those arrays
+    unsigned char* q_out;    // GELU epilogues, optional: gelu(h) also as MX fp8 (bytes [M][ldc]) + block scales [N / 128][ld_q] dwords
+    uint32_t* q_scales;
+    long ld_q;
 };
 
 template <int N>
@@ -884,7 +887,46 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                     // C2 = gelu(h); both from the same erf and exp.
                     // WJ_EPI_BIAS_GELU (forward only, e.C2 == NULL): C = gelu(h) and nothing else.
                     bf16x8 gl, gp;
-                    if (e.C2) {                                   // kernel-uniform
+                    if (e.q_out) {                                // kernel-uniform: MX fp8 of gelu(h) for the next GEMM (config 5)
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
+                        float f[8], amax = 0.f;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) { f[x] = bf2f(gl[x]); amax = fmaxf(amax, fabsf(f[x])); }
+                        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));          // 32 columns = 4 lanes of this row
+                        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                        int sc = 0;
+                        if (amax > 0.f) {
+                            int ex;
+                            const float mm = frexpf(amax * (1.0f / 448.0f), &ex);
+                            sc = (mm == 0.5f) ? ex - 1 : ex;
+                            sc = max(-127, min(127, sc));
+                        }
+                        const float inv = __builtin_amdgcn_ldexpf(1.0f, -sc);
+                        unsigned lo = 0, hi = 0;
+                        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, lo, false);
+                        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+                        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, hi, false);
+                        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+                        *reinterpret_cast<uint2*>(e.q_out + off) = make_uint2(lo, hi);
+                        const unsigned sbyte = (unsigned)(sc + 127);
+                        const int base = lane & ~15;                          // 128 columns = 16 lanes
+                        const unsigned s0 = __shfl(sbyte, base, 64), s1 = __shfl(sbyte, base + 4, 64), s2 = __shfl(sbyte, base + 8, 64),
+                                       s3 = __shfl(sbyte, base + 12, 64);
+                        if ((lane & 15) == 0) e.q_scales[(long)(n >> 7) * e.ld_q + orow] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+                        if (e.C2) {                               // training form: gelu'(h) and the bf16 gelu(h) as well
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) {
+                                float g0, g1;
+                                gelu_both_f(bf2f(v[x]), g0, g1);
+                                gp[x] = f2bf(g1);
+                            }
+                            *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gp;
+                            *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
+                        } else if (e.C) {
+                            *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gl;
+                        }
+                    } else if (e.C2) {                            // kernel-uniform
 #pragma unroll
                         for (int x = 0; x < 8; ++x) {
                             float g0, g1;
@@ -986,7 +1028,7 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_grouped_wgrad_ker
     if (bid >= P.nwg) return;               // padding workgroup
     EpiArgs e;
     e.C = P.C; e.C2 = nullptr; e.bias = nullptr; e.aux = nullptr; e.colsum = nullptr; e.ldc = P.ldc; e.seg_rows = 1; e.seg_valid = 1;
-    e.alpha = 1.f; e.rowmap = nullptr; e.sa = nullptr; e.sb = nullptr; e.lds_a = 0; e.lds_b = 0;
+    e.alpha = 1.f; e.rowmap = nullptr; e.sa = nullptr; e.sb = nullptr; e.lds_a = 0; e.lds_b = 0; e.q_out = nullptr; e.q_scales = nullptr; e.ld_q = 0;
     gemm3_body<true, true, WJ_EPI_ATOMIC_F32, BN, 0, 0>(P.A, P.B, P.lda, P.ldb, P.M, P.N, P.K, P.tiles_n, P.split, P.kps, e, bid, P.nwg);
 }
 
@@ -1001,6 +1043,7 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
     e.rowmap = a->rowmap;
+    e.sa = nullptr; e.sb = nullptr; e.lds_a = 0; e.lds_b = 0; e.q_out = nullptr; e.q_scales = nullptr; e.ld_q = 0;
     auto kern = gemm3_kernel<AT, BT, EPI, BN, SCHED, GATHER>;
     constexpr int lds = Cfg<BN>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1071,6 +1114,7 @@ int launch_fp8(const wj_gemm_fp8_args* a, hipStream_t s) {
     e.C = a->C; e.C2 = a->epilogue == WJ_EPI_BIAS_GELU ? nullptr : a->C2; e.bias = a->bias; e.aux = nullptr; e.ldc = a->ldc; e.colsum = nullptr;
     e.seg_rows = 1; e.seg_valid = 1; e.alpha = 1.f; e.rowmap = nullptr;
     e.sa = (const uint32_t*)a->scale_a; e.sb = (const uint32_t*)a->scale_b; e.lds_a = a->ld_scale_a; e.lds_b = a->ld_scale_b;
+    e.q_out = (unsigned char*)a->q_out; e.q_scales = (uint32_t*)a->q_scales; e.ld_q = a->ld_q_scale;
     auto kern = gemm3_kernel<false, false, EPI, 256, 3, 0>;
     constexpr int lds = Cfg<256>::LDS_BYTES;     // 135168 >= ring (128 KiB) + two parities of block scales (4 KiB)
     static_assert(lds >= 131072 + 4096, "LDS budget of the MX fp8 loop");
@@ -1084,10 +1128,12 @@ int launch_fp8(const wj_gemm_fp8_args* a, hipStream_t s) {
 
 extern "C" int wj_gemm_mxfp8(const wj_gemm_fp8_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
-    if (!a || !a->A || !a->B || !a->C || !a->scale_a || !a->scale_b) return WJ_ERR_ARG;
+    if (!a || !a->A || !a->B || !a->scale_a || !a->scale_b) return WJ_ERR_ARG;
+    if (!a->C && !(a->epilogue == WJ_EPI_BIAS_GELU && a->q_out)) return WJ_ERR_ARG;
+    if (a->q_out && (!a->q_scales || (a->N % 128) || a->ld_q_scale < a->M || a->epilogue == WJ_EPI_BF16)) return WJ_ERR_ARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 256) || (a->N & 7) || (a->ldc & 7) || (a->lda & 15) || (a->ldb & 15)) return WJ_ERR_ARG;
     if (a->ld_scale_a < a->M || a->ld_scale_b < a->N) return WJ_ERR_ARG;
-    if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->scale_a | (uintptr_t)a->scale_b) & 15) return WJ_ERR_ARG;
+    if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->scale_a | (uintptr_t)a->scale_b | (uintptr_t)a->q_out) & 15) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_BIAS_GELU2 && !a->C2) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     switch (a->epilogue) {

@@ -115,11 +115,38 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
                     gs2 = fmaf(y[e], y[e], gs2);
                 }
                 if (a.y_f32) *reinterpret_cast<f32x4*>(a.y_f32 + (long)m * D + col) = y;
-                if (a.y_bf16) {
-                    bf16x4 o;
+                bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f2bf(y[e]);
-                    *reinterpret_cast<bf16x4*>((bf16_t*)a.y_bf16 + (long)m * D + col) = o;
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(y[e]);
+                if (a.y_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.y_bf16 + (long)m * D + col) = o;
+                if (a.y_fp8) {
+                    // MX fp8 of bf16(y), as wj_quantize_mxfp8 defines it: a 32-column block = 8 consecutive lanes of this chunk, the
+                    // four block scales of a 128-column K tile = 32 lanes -> one dword [kt][row] (D % 128 == 0: every lane of a
+                    // block / K tile is live together, so the shuffles below are uniform)
+                    float f[4], amax = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { f[e] = bf2f(o[e]); amax = fmaxf(amax, fabsf(f[e])); }
+                    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                    int sc = 0;
+                    if (amax > 0.f) {
+                        int ex;
+                        const float mm = frexpf(amax * (1.0f / 448.0f), &ex);
+                        sc = (mm == 0.5f) ? ex - 1 : ex;
+                        sc = max(-127, min(127, sc));
+                    }
+                    const float inv = __builtin_amdgcn_ldexpf(1.0f, -sc);
+                    unsigned w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, w, true);
+                    *reinterpret_cast<unsigned*>((unsigned char*)a.y_fp8 + (long)m * D + col) = w;
+                    const unsigned sb = (unsigned)(sc + 127);
+                    const int base = lane & ~31;
+                    const unsigned s0 = __shfl(sb, base, 64), s1 = __shfl(sb, base + 8, 64), s2 = __shfl(sb, base + 16, 64),
+                                   s3 = __shfl(sb, base + 24, 64);
+                    if ((lane & 31) == 0)
+                        ((uint32_t*)a.y_fp8_scales)[(long)(col / 128) * a.ld_fp8_scale + m] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
                 }
             }
         }
@@ -351,6 +378,7 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
     if (a->in_seg > 0 && a->in_valid <= 0) return WJ_ERR_ARG;
     if (a->in_chan > 1 && (a->in_seg <= 0 || a->M % (a->in_chan * a->in_valid))) return WJ_ERR_ARG;
     if (a->group_stats && a->group_rows <= 0) return WJ_ERR_ARG;
+    if (a->y_fp8 && (!a->y_fp8_scales || (a->D % 128) || a->ld_fp8_scale < a->M)) return WJ_ERR_ARG;
     const bool half = (a->D % 128 == 0) && (a->D % 256 != 0) && a->D <= 384;   // 128 / 384: 32 lanes per row
     const int rpw = half ? 2 : 1;
     int grid = (a->M + 4 * rpw - 1) / (4 * rpw);

@@ -450,11 +450,13 @@ class JepaEngine:
         self.lf = _empty(M, c.d_enc, dtype=f32, device=dev)
         self.lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         # fp8 mode: one activation scratch (e4m3 bytes + block scales) per stack (the teacher runs beside the student)
-        self._a8 = {}
+        self._a8, self._a8s = {}, {}
         for tag, (m, d) in dict(tea=(M, c.d_enc), enc=(M, c.d_enc), dec=(Mp if train else 0, c.d_dec)).items():
             if m > 0:
                 self._a8[tag] = (_empty(m, 4 * d, dtype=torch.uint8, device=dev),
                                  torch.zeros(ops.fp8_scale_dwords(m, 4 * d), dtype=torch.int32, device=dev))
+                self._a8s[tag] = (_empty(m, d, dtype=torch.uint8, device=dev),
+                                  torch.zeros(ops.fp8_scale_dwords(m, d), dtype=torch.int32, device=dev))
         # scratch stack (teacher / inference): one layer's worth, reused
         self.scratch = self._alloc_stack(M, c.d_enc, c.h_enc, N, 1)[0]
         self.enc_out = _empty(M, c.d_enc, dtype=f32, device=dev)
@@ -514,14 +516,27 @@ class JepaEngine:
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
                    mask: Optional[torch.Tensor], seq: Optional[Tuple[torch.Tensor, int]] = None, save: bool = True,
                    x2_out: Optional[torch.Tensor] = None, x2_stats: Optional[torch.Tensor] = None,
-                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, stack: str = "enc") -> None:
+                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, stack: str = "enc", xq_ready: bool = False) -> bool:
         """Post-norm layer: x1 = LN1(x + out_proj(attn(in_proj(x)))); x2 = LN2(x1 + linear2(gelu(linear1(x1)))).
         `seq` = (offsets int32 [B+1], longest sequence) selects the ragged form: M packed rows, no key mask.
         save=False (teacher / inference): nothing is kept for a backward (no gelu' output, no softmax statistics).
         sub = (rows int32 [Ms], inverse int32 [M], Ms): only these rows continue after the attention (the last predictor layer:
-        context rows are keys / values there and nothing reads their outputs)."""
+        context rows are keys / values there and nothing reads their outputs).
+        xq_ready / return value (fp8 mode): the stack's small fp8 buffer already / now holds this layer's input / output."""
         eps = self.cfg.ln_eps
-        self._linear_fwd(stack, xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, bias=w.bqkv)
+        # fp8 mode with an eligible width (K = D a multiple of 256): the GEMM inputs are produced directly in the MX fp8 operand
+        # format by their producers -- LayerNorm (x1 for linear1, x2 for the next layer's in_proj) and linear1's GELU epilogue
+        # (for linear2); only the attention output and the very first layer input go through wj_quantize_mxfp8
+        f8 = self.fp8 and w.wqkv in self._w8
+        if not f8:
+            xq_ready = False
+            self._linear_fwd(stack, xb_in, w.wqkv, a.qkv, M=M, N=3 * D, K=D, bias=w.bqkv)
+        else:
+            qb, sb = self._a8[stack]             # [M][4D] bytes: gelu(h)
+            qs, ss = self._a8s[stack]            # [M][D] bytes: x2 -> attention output -> x1 -> x2 (one stream: strictly sequential)
+            if not xq_ready:
+                ops.quantize_mxfp8(xb_in, qs, ss, M=M, K=D, ldx=D, ldq=D, ld_scale=M)
+            self._gemm8(qs, ss, w.wqkv, a.qkv, M=M, N=3 * D, K=D, bias=w.bqkv)
         if seq is not None:
             ops.attn_fwd(a.qkv, a.o, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], lse=a.lse if save else None)
         else:
@@ -532,17 +547,36 @@ class JepaEngine:
             ops.mask_gather_rows(a.o, rows, self.tail_o, n_rows=M, D=D, elem_bytes=2)
             ops.mask_gather_rows(x_in, rows, self.tail_x, n_rows=M, D=D, elem_bytes=4)
             o_in, x_in = self.tail_o, self.tail_x
-        self._linear_fwd(stack, o_in, w.wo, a.p, M=M, N=D, K=D, bias=w.bo)
-        ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1)
-        if save:
-            self._linear_fwd(stack, a.x1b, w.w1, a.h, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2, C2=a.g)
+        f8_out = dict(y_fp8=qs, y_fp8_scales=ss, ld_fp8_scale=M) if f8 else {}
+        if f8:
+            ops.quantize_mxfp8(o_in, qs, ss, M=M, K=D, ldx=D, ldq=D, ld_scale=M)
+            self._gemm8(qs, ss, w.wo, a.p, M=M, N=D, K=D, bias=w.bo)
         else:
-            self._linear_fwd(stack, a.x1b, w.w1, a.g, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU)
-        self._linear_fwd(stack, a.g, w.w2, a.f, M=M, N=D, K=4 * D, bias=w.b2)
+            self._linear_fwd(stack, o_in, w.wo, a.p, M=M, N=D, K=D, bias=w.bo)
+        ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1, **f8_out)
+        if f8:
+            gq = dict(q_out=qb, q_scales=sb, ld_q_scale=M)
+            if save:
+                self._gemm8(qs, ss, w.w1, a.h, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2, C2=a.g, **gq)
+            else:                                              # teacher / inference: gelu(h) exists in fp8 only
+                self._gemm8(qs, ss, w.w1, None, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU, **gq)
+            self._gemm8(qb, sb, w.w2, a.f, M=M, N=D, K=4 * D, bias=w.b2)
+        else:
+            if save:
+                self._linear_fwd(stack, a.x1b, w.w1, a.h, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU2, C2=a.g)
+            else:
+                self._linear_fwd(stack, a.x1b, w.w1, a.g, M=M, N=4 * D, K=D, bias=w.b1, epilogue=ops.EPI_BIAS_GELU)
+            self._linear_fwd(stack, a.g, w.w2, a.f, M=M, N=D, K=4 * D, bias=w.b2)
         # x2_out / x2_stats (teacher): the layer output goes to its own buffer and its per-clip (sum, sum of squares) is
         # accumulated on the way, so that the targets are ONE pass over the kept layers (wj_instnorm_mean)
         ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2 if x2_out is None else x2_out, y_bf16=a.x2b,
-                          mean=a.m2, rstd=a.r2, group_stats=x2_stats, group_rows=self.T if x2_stats is not None else 0)
+                          mean=a.m2, rstd=a.r2, group_stats=x2_stats, group_rows=self.T if x2_stats is not None else 0, **f8_out)
+        return f8 and sub is None              # the small fp8 buffer now holds x2 for the next layer of this stack
+
+    def _gemm8(self, q, sc, w_ptr: int, out, *, M: int, N: int, K: int, bias, epilogue: int = ops.EPI_BF16, C2=None, **extra) -> None:
+        w8 = self._w8[w_ptr]
+        ops.gemm_mxfp8(q, w8[0], sc, w8[1], out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ld_scale_a=M, ld_scale_b=N, epilogue=epilogue, C2=C2,
+                       bias=bias, **extra)
 
     def _wgrad(self, dY, X, gW, n_out: int, k_in: int, m_tok: int) -> None:
         """gW[n_out, k_in] += dY[m_tok, n_out]^T @ X[m_tok, k_in]"""
@@ -684,16 +718,18 @@ class JepaEngine:
             ops.mask_gather_rows(self.lf, plan.keep, self.enc_in, n_rows=n_ctx, D=De, elem_bytes=4)
             ops.mask_gather_rows(self.lf_b, plan.keep, self.enc_in_b, n_rows=n_ctx, D=De, elem_bytes=2)
             x, xb = self.enc_in, self.enc_in_b
+            xq = False
             for w, a in zip(self.enc_layers, self.enc_acts):
-                self._layer_fwd(w, a, x, xb, Me, De, c.h_enc, N, None, eseq)
+                xq = self._layer_fwd(w, a, x, xb, Me, De, c.h_enc, N, None, eseq, xq_ready=xq)
                 x, xb = a.x2, a.x2b
             ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=Me, D=De, eps=c.norm_eps,
                               y_bf16=self.ctx_in, mean=self.enc_fm, rstd=self.enc_fr)
         else:
             # student encoder over every token (keys restricted to the context), then the boolean-mask gather
             x, xb = self.lf, self.lf_b
+            xq = False
             for w, a in zip(self.enc_layers, self.enc_acts):
-                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, plan.ctx_u8)
+                xq = self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, plan.ctx_u8, xq_ready=xq)
                 x, xb = a.x2, a.x2b
             ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=M, D=De, eps=c.norm_eps,
                               y_f32=self.enc_out, y_bf16=self.enc_out_b, mean=self.enc_fm, rstd=self.enc_fr)
@@ -712,9 +748,11 @@ class JepaEngine:
         x, xb = self.dec_in, self.dec_in_b
         self.tail = (plan.tgt_rows, plan.tgt_inv, plan.n_tgt) if (self.ragged_step and self.trim_tail and plan.n_tgt > 0) else None
         Mo = Md                          # rows that leave the predictor
+        xq = False
         for i, (w, a) in enumerate(zip(self.dec_layers, self.dec_acts)):
             last = i == c.l_dec - 1
-            self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq, sub=self.tail if last else None, stack="dec")
+            xq = self._layer_fwd(w, a, x, xb, Md, Dd, c.h_dec, N * G, plan.vis_u8, dseq, sub=self.tail if last else None, stack="dec",
+                                 xq_ready=xq)
             x, xb = a.x2, a.x2b
         if self.tail is not None:
             Mo = plan.n_tgt
@@ -756,14 +794,15 @@ class JepaEngine:
         x, xb = self.lf, self.lf_b
         fused = 1 < c.top_k <= 8
         kept = 0
+        xq = False
         for i, w in enumerate(self.tea_layers):
             keep = c.l_enc - i <= c.top_k
             if keep and fused:
-                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, x2_out=self.tea_keep[kept], x2_stats=self.tea_stats[kept],
-                                stack="tea")
+                xq = self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, x2_out=self.tea_keep[kept],
+                                     x2_stats=self.tea_stats[kept], stack="tea", xq_ready=xq)
                 x, xb = self.tea_keep[kept], a.x2b
             else:
-                self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, stack="tea")
+                xq = self._layer_fwd(w, a, x, xb, M, De, c.h_enc, N, None, save=False, stack="tea", xq_ready=xq)
                 # ping-pong: the next layer reads x2/x2b while writing x1.. of the same scratch set, then x2 again;
                 # x2 is only overwritten by the LAST kernel of the layer, after its readers have run (stream order).
                 x, xb = a.x2, a.x2b
@@ -992,8 +1031,9 @@ class JepaEngine:
         self._frontend(audio)
         a = self.scratch
         x, xb = self.lf, self.lf_b
+        xq = False
         for w in self.enc_layers:
-            self._layer_fwd(w, a, x, xb, self.M, c.d_enc, c.h_enc, N, key_mask_u8, save=False)
+            xq = self._layer_fwd(w, a, x, xb, self.M, c.d_enc, c.h_enc, N, key_mask_u8, save=False, xq_ready=xq)
             x, xb = a.x2, a.x2b
         ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=self.M, D=c.d_enc, eps=c.norm_eps,
                           y_f32=self.enc_out)

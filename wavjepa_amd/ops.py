@@ -85,11 +85,13 @@ def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, 
 
 
 def gemm_mxfp8(A8: Ptr, B8: Ptr, scale_a: Ptr, scale_b: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
-               ld_scale_a: int, ld_scale_b: int, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None,
-               stream: Optional[int] = None) -> None:
-    """C = A . B^T on block-scaled e4m3 operands (see include/wavjepa_hip.h: wj_gemm_mxfp8)."""
+               ld_scale_a: int, ld_scale_b: int, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, q_out: Ptr = None,
+               q_scales: Ptr = None, ld_q_scale: int = 0, stream: Optional[int] = None) -> None:
+    """C = A . B^T on block-scaled e4m3 operands (see include/wavjepa_hip.h: wj_gemm_mxfp8).  q_out / q_scales: the GELU epilogues
+    also emit gelu(h) as MX fp8 (C may then be None for EPI_BIAS_GELU)."""
     _run("wj_gemm_mxfp8", "wj_gemm_fp8_args", stream, A=_p(A8), B=_p(B8), scale_a=_p(scale_a), scale_b=_p(scale_b), C=_p(C), C2=_p(C2),
-         bias=_p(bias), lda=lda, ldb=ldb, ldc=ldc, ld_scale_a=ld_scale_a, ld_scale_b=ld_scale_b, M=M, N=N, K=K, epilogue=epilogue)
+         bias=_p(bias), q_out=_p(q_out), q_scales=_p(q_scales), lda=lda, ldb=ldb, ldc=ldc, ld_scale_a=ld_scale_a, ld_scale_b=ld_scale_b,
+         ld_q_scale=ld_q_scale, M=M, N=N, K=K, epilogue=epilogue)
 
 
 def quantize_mxfp8(x: Ptr, q: Ptr, scales: Ptr, *, M: int, K: int, ldx: int, ldq: int, ld_scale: int, stream: Optional[int] = None) -> None:
@@ -139,11 +141,12 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 # ---------------------------------------------------------------------------------------------------------- norms
 def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, r: Ptr = None, y_f32: Ptr = None,
                   y_bf16: Ptr = None, mean: Ptr = None, rstd: Ptr = None, x_is_bf16: bool = False, in_seg: int = 0,
-                  in_valid: int = 0, group_stats: Ptr = None, group_rows: int = 0, in_chan: int = 0,
-                  stream: Optional[int] = None) -> None:
+                  in_valid: int = 0, group_stats: Ptr = None, group_rows: int = 0, in_chan: int = 0, y_fp8: Ptr = None,
+                  y_fp8_scales: Ptr = None, ld_fp8_scale: int = 0, stream: Optional[int] = None) -> None:
     _run("wj_layernorm_fwd", "wj_ln_fwd_args", stream, x=_p(x), r=_p(r), gamma=_p(gamma), beta=_p(beta), y_f32=_p(y_f32),
-         y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), group_stats=_p(group_stats), M=M, D=D, x_is_bf16=int(x_is_bf16),
-         in_seg=in_seg, in_valid=in_valid, group_rows=group_rows, in_chan=in_chan, eps=eps)
+         y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), group_stats=_p(group_stats), y_fp8=_p(y_fp8), y_fp8_scales=_p(y_fp8_scales),
+         ld_fp8_scale=ld_fp8_scale, M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, group_rows=group_rows,
+         in_chan=in_chan, eps=eps)
 
 
 def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
