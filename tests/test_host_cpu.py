@@ -359,3 +359,20 @@ print("LIGHTNING_OK")
 """ % (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "LIGHTNING_OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_integration_md_ctypes_stub_matches_the_library():
+    """The reference-side binding printed in INTEGRATION.md section 2 must describe the struct the built library expects."""
+    from wavjepa_amd import _abi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = text.split("```python")[2].split("```")[0]
+    decl = stub[stub.index("class wj_ln_fwd_args"):stub.index("assert _lib.wj_struct_size")]
+    ns = {"ctypes": ctypes}
+    exec(decl, ns)
+    mirror = ns["wj_ln_fwd_args"]
+    assert ctypes.sizeof(mirror) == _abi.load().wj_struct_size(b"wj_ln_fwd_args")
+    generated = _abi.STRUCTS["wj_ln_fwd_args"]
+    assert [n for n, _ in mirror._fields_] == [n for n, _ in generated._fields_]
+    assert f"ABI version {_abi.DEFINES['WJ_ABI_VERSION']}" in text
