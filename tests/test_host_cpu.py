@@ -376,3 +376,28 @@ def test_integration_md_ctypes_stub_matches_the_library():
     generated = _abi.STRUCTS["wj_ln_fwd_args"]
     assert [n for n, _ in mirror._fields_] == [n for n, _ in generated._fields_]
     assert f"ABI version {_abi.DEFINES['WJ_ABI_VERSION']}" in text
+
+
+def test_compiled_kernels_have_no_mfma_result_read_across_a_branch(tmp_path):
+    """hipcc was seen to leave ONE wait state between an MFMA and the first VALU read of its result when a branch lay between them
+    (attention forward, round 2: run-dependent softmax sums).  tools/mfma_hazard_scan.py walks the gfx950 assembly of every source
+    for that pattern; it must stay clean."""
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    from wavjepa_amd import build as B
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = B._hipcc()
+
+    def scan(name):
+        asm = str(tmp_path / (name + ".s"))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", "-o", asm,
+                            os.path.join(root, "wavjepa_amd", "csrc", name + ".hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_scan.py"), asm], capture_output=True, text=True)
+        return name, r.returncode, r.stdout[-1500:]
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for name, rc, out in ex.map(scan, ["attention", "gemm", "norm", "conv0", "fp8"]):
+            assert rc == 0, (name, out)

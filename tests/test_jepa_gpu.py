@@ -188,6 +188,41 @@ def test_forward_backward_parity_400_tokens(golden_dir, ragged):
         assert e < 3e-2, (g, e)
 
 
+def test_forward_backward_parity_seven_layer_wav2vec2_spec(golden_dir):
+    """The reference's other extractor config (`configs/extractor/wav2vec2.yaml:1`: seven conv layers, stride 320):
+    4.02 s clips -> 200 tokens through the same kernels, ragged student / predictor, against the oracle."""
+    spec = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2
+    cfg = dict(SMALL, conv_spec=spec)
+    m, P = build(cfg, seconds=4.02, tokens=200)
+    assert m.total_patches == 200
+    n_samples = m.target_length
+    ctx, tgt, vis = masks(golden_dir, 3)
+    audio = torch.from_numpy(synth.synth_audio(3, 1, n_samples, seed=23)).to(torch.bfloat16).to(dev())
+    out = m(audio, ctx, tgt, vis)
+    assert m._engine.ragged_step
+    names = J.trainable_names(P)
+    for k in names:
+        P[k].requires_grad_(True)
+    ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(cfg))
+    lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
+    assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
+    assert rel(out["local_features"].float(), ref["local_features"].float()) < 1e-2
+    assert rel(out["targets"].float(), ref["targets"].float()) < 1e-2
+    out["loss"].backward()
+    ref["loss"].backward()
+    got = dict(m.named_parameters())
+    num, den = {}, {}
+    for k in names:
+        g = group_of(k)
+        a, b = got[k].grad.double(), P[k].grad.double()
+        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
+        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
+    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    print("seven-layer spec: loss", lo, lr_, "grad rel errors per group:", errs)
+    for g, e in errs.items():
+        assert e < 3e-2, (g, e)
+
+
 def test_forward_backward_parity_two_channel_audio(golden_dir):
     """Binaural input through the 2-channel first conv (`in_channels=2`, 20 taps in conv0)."""
     m, P = build(SMALL, in_channels=2)

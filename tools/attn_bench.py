@@ -30,6 +30,9 @@ def timeit(fn, n=5, reps=3):
 
 
 torch.manual_seed(0)
+import random  # noqa: E402
+random.seed(0)
+np.random.seed(0)
 masker = TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10, target_prob=0.25,
                                 target_length=10, ratio_cutoff=0.1)
 ctx, tgt, vis = masker(256, 200, 1)

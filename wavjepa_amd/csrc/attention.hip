@@ -19,6 +19,7 @@ constexpr int MAX_TILES = 14;  // 16-row tiles of the default instantiation: T <
 constexpr int MAX_TILES_LONG = 26;  // T <= 416 (4.01 s clips -> 400 tokens): K + V images of a 64-wide head = 133 KB of LDS
 constexpr int NWB64 = 4, NWB32 = 4;   // backward waves per workgroup (more waves measured slower: 339 -> 439 us at hd 64)
 constexpr int NWF_LONG = 7;    // forward, T > 128: 13 query tiles over 7 waves (2,2,2,2,2,2,1) instead of 4 (4,3,3,3)
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr int NWF_SHORT = 4;   // forward, T <= 128 (ragged student / predictor): <= 2 tiles per wave, twice the workgroups per CU
 
 template <int HD> struct Img {
@@ -108,6 +109,16 @@ __device__ __forceinline__ float group_max(float v) {  // over the 4 lane groups
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
 }
+// Sum over the 16 lanes of a DPP row (same lane >> 4), every lane gets the total: four v_add_f32 with DPP operands (quad swaps,
+// then half-row and row mirrors -- once a quad holds its sum in all four lanes any pairing of quads will do) instead of four
+// ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
 __device__ __forceinline__ float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
@@ -148,40 +159,51 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
         madd[k] = (k < T && !(km && km[k])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const float scale = rsqrtf((float)HD);
+    // softmax in the exp2 domain on the RAW scores: max over s, then p = exp2(s * (scale * log2 e) - max * (scale * log2 e)) -- one
+    // fma + v_exp_f32 per score.  (A wave-uniform branch that skipped the mask on tiles without one put a taken branch between an
+    // MFMA and the first VALU read of its result; hipcc left one wait state there and the kernel returned run-dependent sums.)
+    const float scale = rsqrtf((float)HD), scale2 = scale * LOG2E;
     for (int qt = wave; qt < nkt; qt += NWF) {
         bf16x8 qn[KS];                   // next tile's fragments: issued now, consumed at the end of this iteration
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NWF) * 16, (qt + NWF < nkt) ? T : 0, ks, lane);
         f32x4 s[MT];
         float mx = -INFINITY;
+        // key tiles go in PAIRS (one 32-row chunk of the image; the second tile of the last chunk may be all padding: zero K rows
+        // under a -inf mask): half the branches, and two independent MFMA chains for the scheduler to interleave
 #pragma unroll
-        for (int kt = 0; kt < MT; ++kt) {
-            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kt < nkt) {
+        for (int c = 0; c < MT / 2; ++c) {
+            s[2 * c] = s[2 * c + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nch) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(kimg, kt * 16, ks, lane), qf[ks], s[kt], 0, 0, 0);
-                const f32x4 ma = *reinterpret_cast<const f32x4*>(madd + kt * 16 + 4 * g);
+                for (int u = 0; u < 2; ++u) {
+                    const int kt = 2 * c + u;
+                    s[kt] = *reinterpret_cast<const f32x4*>(madd + kt * 16 + 4 * g);   // 0 / -inf: the mask rides in as the MFMA's C operand
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[kt][r] = s[kt][r] * scale + ma[r];
-                    mx = fmaxf(mx, s[kt][r]);
+                    for (int ks = 0; ks < KS; ++ks)
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(kimg, kt * 16, ks, lane), qf[ks], s[kt], 0, 0, 0);
                 }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[2 * c + u][r]);
             }
         }
         mx = group_max(mx);
         const float msafe = (mx == -INFINITY) ? 0.f : mx;  // fully masked row: all p = 0 (the reference yields NaN)
+        const float m2 = msafe * scale2;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < MT; ++kt) {
-            if (kt < nkt) {
+        for (int c = 0; c < MT / 2; ++c) {
+            if (c < nch) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(s[kt][r] - msafe);
-                    s[kt][r] = p;
-                    sum += p;
-                }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[2 * c + u][r], scale2, -m2));
+                        s[2 * c + u][r] = p;
+                        sum += p;
+                    }
             }
         }
         sum = group_sum(sum);
@@ -192,9 +214,8 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
 #pragma unroll
         for (int c = 0; c < MT / 2; ++c) {
             if (c < nch) {
-                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
                 // probabilities are normalised BEFORE the bf16 rounding (as a materialised softmax would be)
-                const bf16x8 pf = pack_tiles(s[2 * c] * inv, (2 * c + 1 < nkt) ? s[2 * c + 1] * inv : z);
+                const bf16x8 pf = pack_tiles(s[2 * c] * inv, s[2 * c + 1] * inv);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(vimg, c, dt * 16, lane), pf, o[dt], 0, 0, 0);
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
                 *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) = ov;
             }
             if (a.lse && g == 0)
-                a.lse[a.seq_off ? (row0 + q) * H + h : ((long)b * H + h) * T + q] = sum > 0.f ? msafe + __logf(sum) : INFINITY;
+                a.lse[a.seq_off ? (row0 + q) * H + h : ((long)b * H + h) * T + q] = sum > 0.f ? fmaf(msafe, scale, __logf(sum)) : INFINITY;
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -447,6 +468,251 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
     }
 }
 
+// Backward for SHORT sequences (T <= 128: ragged student / predictor), one global round trip per workgroup.
+// The general kernel above walks four dependent fetches (K/V images -> statistics rows -> Q/dO fragments -> K/V fragments again),
+// each a full HBM/L2 latency with only 4 workgroups per CU to hide it (stamps: a predictor workgroup lives ~20 us for ~2 us of
+// issue).  Here every wave fetches, at entry, the MFMA row fragments of ITS OWN <= 2 tiles of K, V, Q, dO and O (lane (i,g) = row i,
+// 16-B chunk g: exactly the B-operand layout) plus lse / key mask for those rows, and everything downstream is fed from them:
+//   * the K / V fragments are written to the LDS images for phase A and stay in registers as phase B's own-tile operands,
+//   * the Q / dO fragments are phase A's own-tile operands and are written to the images once phase A is done,
+//   * delta = rowsum(dO . O) falls out of the dO / O fragments with two cross-lane adds.
+template <int HD, int NWB, int MT, bool MASKED>
+__global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kernel(wj_attn_bwd_args a) {
+    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16, TPW = MT / NWB;
+    static_assert(MT % NWB == 0, "tiles are dealt to waves round-robin");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, D = H * HD;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = wg / H, h = wg - b * H;
+    int T = a.T;
+    long row0 = (long)b * a.T;
+    if (a.seq_off) {
+        row0 = a.seq_off[b];
+        T = min(a.seq_off[b + 1] - (int)row0, a.T);
+    }
+    const int nt = (T + 15) / 16, KP = ((T + 31) / 32) * 32, nch = KP / 32;
+    char* img0 = smem;                // phase A: K      phase B: Q
+    char* img1 = smem + KP * RS;      // phase A: V      phase B: dO
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * KP * RS);
+    float* delta = lse_s + KP;
+    float* kvalid = delta + KP;
+    float* bsum = kvalid + KP;
+    for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) bsum[x] = 0.f;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const long ld = 3L * D;
+    const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * ld + h * HD;
+    const bf16_t* dO = (const bf16_t*)a.dout + row0 * D + h * HD;
+    const bf16_t* O = (const bf16_t*)a.out + row0 * D + h * HD;
+    bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HD;
+    const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
+
+    bf16x8 kfr[TPW][KS], vfr[TPW][KS], qfr[TPW][KS], dofr[TPW][KS];
+    float lse_r[TPW], delta_r[TPW], kv_r[TPW];
+    {
+        bf16x8 ofr[TPW][KS];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {          // every fetch of the workgroup's life, back to back
+            const int rb = (wave + t * NWB) * 16, row = rb + i;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kfr[t][ks] = row_frag_global(qkv + D, ld, rb, T, ks, lane);
+                vfr[t][ks] = row_frag_global(qkv + 2 * D, ld, rb, T, ks, lane);
+                qfr[t][ks] = row_frag_global(qkv, ld, rb, T, ks, lane);
+                dofr[t][ks] = row_frag_global(dO, D, rb, T, ks, lane);
+                ofr[t][ks] = row_frag_global(O, D, rb, T, ks, lane);
+            }
+            lse_r[t] = INFINITY; kv_r[t] = 0.f;
+            if (row < T) {
+                lse_r[t] = a.lse[a.seq_off ? (row0 + row) * H + h : ((long)b * H + h) * T + row] * LOG2E;
+                kv_r[t] = (km && km[row]) ? 0.f : 1.f;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int rb = (wave + t * NWB) * 16, row = rb + i;
+            float dl = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += bf2f(dofr[t][ks][e]) * bf2f(ofr[t][ks][e]);
+            delta_r[t] = group_sum(dl);
+            if (rb < KP) {                        // rows [T, KP) carry zeros / +inf (fragments of rows >= T are zero)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    *reinterpret_cast<bf16x8*>(img0 + row * RS + (ks * 4 + g) * 16) = kfr[t][ks];
+                    *reinterpret_cast<bf16x8*>(img1 + row * RS + (ks * 4 + g) * 16) = vfr[t][ks];
+                }
+                if (g == 0) { lse_s[row] = lse_r[t]; delta[row] = delta_r[t]; kvalid[row] = kv_r[t]; }
+            }
+        }
+    }
+    __syncthreads();
+    // p = exp(s * scale - lse) = exp2(s * (scale * log2 e) - lse * log2 e): one fma + v_exp_f32 per score; the 1/sqrt(hd) of dS is
+    // applied once to the dQ / dK accumulators (as the flash kernels do) instead of to every dS element.
+    // Without a key mask nothing needs masking at all: K / V rows >= T are zero in the images, so a padding key adds 0 to dQ, and the
+    // dK / dV rows of padding keys are never stored; padding QUERIES have lse = +inf, p = 0.
+    const float scale = rsqrtf((float)HD), scale2 = scale * LOG2E;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- phase A: dQ of this wave's query tiles
+    f32x4 csq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) csq[dt] = zero4;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int qt = wave + t * NWB;
+        if (qt < nt) {
+            f32x4 dq[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = zero4;
+#pragma unroll
+            for (int c = 0; c < MT / 2; ++c) {
+                if (c < nch) {
+                    f32x4 ds2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int kt = 2 * c + u;
+                        ds2[u] = zero4;
+                        if (kt < nt) {
+                            f32x4 s = zero4, dp = zero4;
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img0, kt * 16, ks, lane), qfr[t][ks], s, 0, 0, 0);
+                                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img1, kt * 16, ks, lane), dofr[t][ks], dp, 0, 0, 0);
+                            }
+                            f32x4 kv;
+                            if constexpr (MASKED) kv = *reinterpret_cast<const f32x4*>(kvalid + kt * 16 + 4 * g);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -lse_r[t]));
+                                if constexpr (MASKED) p *= kv[r];
+                                ds2[u][r] = p * (dp[r] - delta_r[t]);
+                            }
+                        }
+                    }
+                    const bf16x8 dsf = pack_tiles(ds2[0], ds2[1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img0, c, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
+                }
+            }
+            const int q = qt * 16 + i;
+            if (q < T) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ov[r] = f2bf(dq[dt][r] * scale); csq[dt][r] += bf2f(ov[r]); }
+                    *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
+                }
+            }
+        }
+    }
+    if (a.dbias) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row16_sum(csq[dt][r]);
+                if (i == 0) atomicAdd(bsum + dt * 16 + 4 * g + r, v);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int rb = (wave + t * NWB) * 16, row = rb + i;
+        if (rb < KP) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                *reinterpret_cast<bf16x8*>(img0 + row * RS + (ks * 4 + g) * 16) = qfr[t][ks];
+                *reinterpret_cast<bf16x8*>(img1 + row * RS + (ks * 4 + g) * 16) = dofr[t][ks];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: dK, dV of this wave's key tiles
+    f32x4 csk[DT], csv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) csk[dt] = csv[dt] = zero4;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int kt = wave + t * NWB;
+        if (kt < nt) {
+            f32x4 dk[DT], dv[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = zero4;
+#pragma unroll
+            for (int c = 0; c < MT / 2; ++c) {
+                if (c < nch) {
+                    f32x4 p2[2], ds2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int qt = 2 * c + u;
+                        p2[u] = ds2[u] = zero4;
+                        if (qt < nt) {
+                            f32x4 s = zero4, dp = zero4;
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img0, qt * 16, ks, lane), kfr[t][ks], s, 0, 0, 0);
+                                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<HD>(img1, qt * 16, ks, lane), vfr[t][ks], dp, 0, 0, 0);
+                            }
+                            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
+                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + qt * 16 + 4 * g);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, -l4[r]));
+                                if constexpr (MASKED) p *= kv_r[t];
+                                p2[u][r] = p;
+                                ds2[u][r] = p * (dp[r] - d4[r]);
+                            }
+                        }
+                    }
+                    const bf16x8 pf = pack_tiles(p2[0], p2[1]);
+                    const bf16x8 dsf = pack_tiles(ds2[0], ds2[1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img1, c, dt * 16, lane), pf, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img0, c, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
+                    }
+                }
+            }
+            const int key = kt * 16 + i;
+            if (key < T) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4 ok, ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ok[r] = f2bf(dk[dt][r] * scale); ov[r] = f2bf(dv[dt][r]);
+                        csk[dt][r] += bf2f(ok[r]); csv[dt][r] += bf2f(ov[r]);
+                    }
+                    *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
+                    *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
+                }
+            }
+        }
+    }
+    if (a.dbias) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row16_sum(csk[dt][r]), u = row16_sum(csv[dt][r]);
+                if (i == 0) {
+                    atomicAdd(bsum + HD + dt * 16 + 4 * g + r, v);
+                    atomicAdd(bsum + 2 * HD + dt * 16 + 4 * g + r, u);
+                }
+            }
+        __syncthreads();
+        for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) {
+            const int part = x / HD, d = x - part * HD;
+            a.dbias_ws[(long)b * 3 * D + part * D + h * HD + d] = bsum[x];
+        }
+    }
+}
+
 template <typename K>
 int set_lds(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
@@ -503,8 +769,17 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
         if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 26>), grid, dim3(NWB64 * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 26>), grid, dim3(NWB32 * 64), lds, st, *a);
     } else if (a->T <= 128) {          // ragged student / predictor: at most 8 tiles (6 or 8 waves per workgroup measured 1.5-2x slower)
-        if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 8>), grid, dim3(NWB64 * 64), lds, st, *a);
-        else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 8>), grid, dim3(NWB32 * 64), lds, st, *a);
+        static const int frag = getenv("WJ_ATTN_BWD_FRAG") ? atoi(getenv("WJ_ATTN_BWD_FRAG")) : 3;   // bit 0: hd 32, bit 1: hd 64 (A/B switch)
+        const bool masked = a->key_mask != nullptr;
+        if (a->hd == 64) {
+            if (!(frag & 2)) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 8>), grid, dim3(NWB64 * 64), lds, st, *a);
+            else if (masked) hipLaunchKernelGGL((attn_bwd_frag_kernel<64, NWB64, 8, true>), grid, dim3(NWB64 * 64), lds, st, *a);
+            else hipLaunchKernelGGL((attn_bwd_frag_kernel<64, NWB64, 8, false>), grid, dim3(NWB64 * 64), lds, st, *a);
+        } else {
+            if (!(frag & 1)) hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 8>), grid, dim3(NWB32 * 64), lds, st, *a);
+            else if (masked) hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 8, true>), grid, dim3(NWB32 * 64), lds, st, *a);
+            else hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 8, false>), grid, dim3(NWB32 * 64), lds, st, *a);
+        }
     } else if (a->hd == 64) {
         hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 14>), grid, dim3(NWB64 * 64), lds, st, *a);
     } else {
