@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 7
+#define WJ_ABI_VERSION 8
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -517,6 +517,47 @@ typedef struct {
     int32_t B, S, C, L_full, length;
 } wj_crop_args;
 int wj_crop_normalize_bf16(const wj_crop_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Scene augmentation (data_modules/scene_module/generate_scenes_batch.py), fp32.
+ *
+ * wj_rir_convolve: batched room-impulse-response convolution, "full" convolution cut to the input length
+ *   (convolve_with_rir, generate_scenes_batch.py:12-44 = torchaudio fftconvolve(waveform, rir[c])[..., :T] per channel c):
+ *       y[b][c][t] = sum_{k < L, k <= t} x[b][t - k] * h[b][c][k]          t < T
+ *   x f32 [B][T];  h f32, element (b, c, k) at h[b*h_stride_b + c*h_stride_c + k] (a channel slice of a [B][n][C'][L] stack needs
+ *   no copy);  y f32 [B][C][T], overwritten, or added to when `accumulate` (aggregate_noise, :47-71: sum over noise sources).
+ *   Uniformly partitioned overlap-save with an in-LDS block FFT (fft_size 8192; 1024 is accepted so that tests can cross many
+ *   blocks / partitions at small sizes; 0 = 8192).  workspace: wj_workspace_bytes("wj_rir_convolve", args) bytes.
+ *
+ * wj_snr_mix: segmental-SNR mixing (add_noise, :108-150):
+ *       Ex = sum_{t in [start_b, start_b + length_b)} source^2,  En likewise for noise   (per b, c)
+ *       a = sqrt(Ex / (En + 1e-9) * 10^(-snr_b / 10));   out = source + a * noise
+ *   source / noise / out f32 [B][C][T] (out may alias source); snr f32 [B] (dB); start / length int32 [B];
+ *   workspace: wj_workspace_bytes("wj_snr_mix", args) bytes.  Sums are folded in a fixed order (bit-reproducible).
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const float* x;
+    const float* h;
+    float* y;
+    void* workspace;
+    int64_t h_stride_b, h_stride_c;
+    int32_t B, C, T, L;
+    int32_t accumulate;
+    int32_t fft_size;
+} wj_rir_conv_args;
+int wj_rir_convolve(const wj_rir_conv_args*, void* stream);
+
+typedef struct {
+    const float* source;
+    const float* noise;
+    float* out;
+    const float* snr;
+    const int32_t* start;
+    const int32_t* length;
+    float* workspace;
+    int32_t B, C, T;
+} wj_snr_mix_args;
+int wj_snr_mix(const wj_snr_mix_args*, void* stream);
 
 #ifdef __cplusplus
 }

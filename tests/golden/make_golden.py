@@ -37,6 +37,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from _ref_import import import_reference  # noqa: E402
+import _ref_import as RI  # noqa: E402
 import synth  # noqa: E402
 
 R = import_reference()
@@ -409,8 +410,45 @@ def gen_misc():
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **fx)
 
 
+def gen_scene():
+    """Scene augmentation: the reference's own generate_scenes_batch.py on seeded inputs, all four cases.
+    torchaudio is not installed; its `functional.fftconvolve` is supplied per torchaudio's published definition
+    (irfft(rfft(x, n) * rfft(y, n), n), n = len(x) + len(y) - 1, mode "full") -- everything else is the reference's code."""
+    import importlib.util
+    RI.install_stubs()
+
+    def fftconvolve(x, y, mode="full"):
+        assert mode == "full"
+        n = x.size(-1) + y.size(-1) - 1
+        return torch.fft.irfft(torch.fft.rfft(x, n=n) * torch.fft.rfft(y, n=n), n=n)
+
+    sys.modules["torchaudio"].functional.fftconvolve = fftconvolve
+    spec = importlib.util.spec_from_file_location("ref_scene", os.path.join(RI.REFERENCE_ROOT, "data_modules", "scene_module",
+                                                                            "generate_scenes_batch.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    B, T, L, n = 3, 6000, 700, 2
+    g = torch.Generator().manual_seed(20)
+    src = torch.randn(B, T, generator=g)
+    noise = torch.randn(B, T, generator=g)
+    srir = torch.randn(B, 2, L, generator=g) * torch.exp(-torch.arange(L) / 100.0)
+    nrir = torch.randn(B, n, 2, L, generator=g) * torch.exp(-torch.arange(L) / 150.0)
+    length = torch.tensor([3000, 6000, 1500])
+    start = torch.tensor([100, 0, 2000])
+    snr = torch.tensor([5.0, 0.0, -3.0])
+    fx = dict(source=src.numpy(), noise=noise.numpy(), source_rir=srir.numpy(), noise_rirs=nrir.numpy(), length=length.numpy(),
+              start=start.numpy(), snr=snr.numpy())
+    fx["conv"] = ref.convolve_with_rir(src, srir).numpy()
+    fx["agg"] = ref.aggregate_noise(nrir, noise).numpy()
+    fx["case_rir_noise"] = ref.generate_scene(srir, nrir, src, noise, length, start, snr).numpy()
+    fx["case_rir_only"] = ref.generate_scene(srir, nrir, src, [None], length, start, snr).numpy()
+    fx["case_noise_only"] = ref.generate_scene([None], nrir, src.unsqueeze(1), noise.unsqueeze(1), length, start, snr).numpy()
+    fx["mix_scalar"] = ref.add_noise(src[:1].unsqueeze(1), noise[:1].unsqueeze(1), 7.5, 500, 2500).numpy()   # scalar snr: B = 1 only (:140)
+    np.savez_compressed(os.path.join(HERE, "scene.npz"), **fx)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -424,6 +462,8 @@ if __name__ == "__main__":
         gen_base(masks)
     if "channel" in which:
         gen_channel(masks)
+    if "scene" in which:
+        gen_scene()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

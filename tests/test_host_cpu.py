@@ -69,6 +69,11 @@ def test_product_path_fails_loudly_without_gpu():
         m.get_audio_representation(audio, None)
     with pytest.raises(RuntimeError):
         m.extract_audio(audio)
+    from wavjepa_amd import scene
+    with pytest.raises(RuntimeError):
+        scene.convolve_with_rir(torch.zeros(2, 100), torch.zeros(2, 1, 10))
+    with pytest.raises(RuntimeError):
+        scene.add_noise(torch.zeros(2, 1, 100), torch.zeros(2, 1, 100), torch.zeros(2), torch.zeros(2), torch.zeros(2))
 
 
 class Pinned:

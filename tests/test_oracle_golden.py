@@ -266,3 +266,30 @@ def test_channel_frontend_binaural_positions_and_channel_masks(golden_dir):
     assert np.array_equal(c2.numpy().reshape(3, 2, 200), fx["cb_ctx"].reshape(3, 200, 2).transpose(0, 2, 1))
     assert np.array_equal(t2.numpy().reshape(3, 4, 2, 200), fx["cb_tgt"].reshape(3, 4, 200, 2).transpose(0, 1, 3, 2))
     assert np.array_equal(v2.numpy().reshape(3, 4, 2, 200), fx["cb_vis"].reshape(3, 4, 200, 2).transpose(0, 1, 3, 2))
+
+
+def test_scene_oracle_matches_reference_fixture(golden_dir):
+    """oracle/scene_oracle.py against the reference's own generate_scenes_batch.py (fixture scene.npz): RIR convolution, noise
+    aggregation, segmental-SNR mixing and the cases of generate_scene.  The reference computes in fp32 (tolerance 2e-5 of the
+    output RMS); the oracle's float32 mode must land within the same band."""
+    from oracle import scene_oracle as S
+
+    fx = dict(np.load(os.path.join(golden_dir, "scene.npz")))
+    src, noise, srir, nrir = fx["source"], fx["noise"], fx["source_rir"], fx["noise_rirs"]
+
+    def close(got, ref, tol=2e-5):
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max() / np.sqrt((ref.astype(np.float64) ** 2).mean())
+        assert err < tol, err
+
+    for dt in (np.float64, np.float32):
+        close(S.convolve_with_rir(src, srir, dt), fx["conv"])
+        close(S.aggregate_noise(nrir, noise, dt), fx["agg"])
+        close(S.generate_scene(srir, nrir, src, noise, fx["length"], fx["start"], fx["snr"], dt), fx["case_rir_noise"])
+        close(S.generate_scene(srir, nrir, src, None, fx["length"], fx["start"], fx["snr"], dt), fx["case_rir_only"])
+        close(S.generate_scene(None, nrir, src[:, None], noise[:, None], fx["length"], fx["start"], fx["snr"], dt), fx["case_noise_only"])
+        close(S.add_noise(src[:1, None], noise[:1, None], 7.5, 500, 2500, dt), fx["mix_scalar"])
+    # the full convolution really is the direct sum (independent of any FFT)
+    b, c, t = 1, 1, 4321
+    direct = sum(float(src[b, t - k]) * float(srir[b, c, k]) for k in range(min(t + 1, srir.shape[-1])))
+    assert abs(S.convolve_with_rir(src, srir)[b, c, t] - direct) < 1e-9 * max(1.0, abs(direct))

@@ -66,7 +66,8 @@ def require_gpu() -> None:
 def workspace_bytes(fn: str, **dims) -> int:
     """Scratch bytes entry point `fn` needs for the given dimensions (fields of its argument struct), from the library."""
     struct_name = {"wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
-                   "wj_conv0_gn_gelu_bwd": "wj_conv0_bwd_args", "wj_masked_mse": "wj_mse_args", "wj_grad_sumsq": "wj_sumsq_args"}[fn]
+                   "wj_conv0_gn_gelu_bwd": "wj_conv0_bwd_args", "wj_masked_mse": "wj_mse_args", "wj_grad_sumsq": "wj_sumsq_args",
+                   "wj_rir_convolve": "wj_rir_conv_args", "wj_snr_mix": "wj_snr_mix_args"}[fn]
     a = STRUCTS[struct_name]()
     for k, v in dims.items():
         setattr(a, k, v)
@@ -302,3 +303,18 @@ def crop_normalize_bf16(src: Ptr, starts: Ptr, out: Ptr, *, B: int, S: int, C: i
                         perm_inv: Ptr = None, stream: Optional[int] = None) -> None:
     _run("wj_crop_normalize_bf16", "wj_crop_args", stream, src=_p(src), starts=_p(starts), perm_inv=_p(perm_inv), out=_p(out),
          B=B, S=S, C=C, L_full=L_full, length=length)
+
+
+# ---------------------------------------------------------------------------------------------------------- scene augmentation
+def rir_convolve(x: Ptr, h: Ptr, y: Ptr, workspace: Ptr, *, B: int, C: int, T: int, L: int, h_stride_b: int, h_stride_c: int,
+                 accumulate: bool = False, fft_size: int = 0, stream: Optional[int] = None) -> None:
+    """y[b][c][:T] (+)= (x[b] * h[b][c])[:T]  (generate_scenes_batch.py:12-44); fp32, workspace from workspace_bytes("wj_rir_convolve")."""
+    _run("wj_rir_convolve", "wj_rir_conv_args", stream, x=_p(x), h=_p(h), y=_p(y), workspace=_p(workspace), h_stride_b=h_stride_b,
+         h_stride_c=h_stride_c, B=B, C=C, T=T, L=L, accumulate=int(accumulate), fft_size=fft_size)
+
+
+def snr_mix(source: Ptr, noise: Ptr, out: Ptr, snr: Ptr, start: Ptr, length: Ptr, workspace: Ptr, *, B: int, C: int, T: int,
+            stream: Optional[int] = None) -> None:
+    """out = source + a * noise with the segmental-SNR gain a of generate_scenes_batch.py:108-150."""
+    _run("wj_snr_mix", "wj_snr_mix_args", stream, source=_p(source), noise=_p(noise), out=_p(out), snr=_p(snr), start=_p(start),
+         length=_p(length), workspace=_p(workspace), B=B, C=C, T=T)
