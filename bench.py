@@ -36,20 +36,24 @@ import torch.distributed as dist  # noqa: E402
 CONV_SPEC = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)]
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense; /opt/skills/guides/MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
 MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense, block-scaled (MX) e4m3: the scaled MFMA form is the one that runs at 2x the bf16 rate
-WORKLOADS = {   # name: (seconds per clip, fp8 forward GEMMs)
-    "2s-bf16": (2.01, False),    # BASELINE config 2 / 3: the headline metric
-    "4s-bf16": (4.01, False),    # 400 tokens, bf16
-    "4s-fp8": (4.01, True),      # BASELINE config 5: 400 tokens, MX fp8 forward GEMMs
+WORKLOADS = {   # name: (seconds per clip, fp8 forward GEMMs, binaural scene front-end)
+    "2s-bf16": (2.01, False, False),    # BASELINE config 2 / 3: the headline metric
+    "4s-bf16": (4.01, False, False),    # 400 tokens, bf16
+    "4s-fp8": (4.01, True, False),      # BASELINE config 5: 400 tokens, MX fp8 forward GEMMs
+    "2s-nat": (2.01, False, True),      # BASELINE config 4: scene augmentation + 2-channel front-end (2 x 200 tokens)
 }
 STEP_GFLOP_PER_CLIP = 283.7      # dense algorithmic FLOPs of one step per clip (fwd 118.2 + bwd 165.5)
 
 
-def build_model(device, seed: int, seconds: float = 2.01):
-    from wavjepa_amd.extractors import ConvFeatureExtractor
+def build_model(device, seed: int, seconds: float = 2.01, nat: bool = False):
+    from wavjepa_amd.extractors import ConvChannelFeatureExtractor, ConvFeatureExtractor
     from wavjepa_amd.jepa import JEPA
     from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
     torch.manual_seed(seed)
-    ext = ConvFeatureExtractor(conv_layers_spec=CONV_SPEC, in_channels=1)
+    if nat:      # WavJEPA-Nat: each ear through its own mono conv stack, tokens of both channels in one sequence
+        ext = ConvChannelFeatureExtractor(conv_layers_spec=CONV_SPEC, in_channels=2, share_weights_over_channels=False)
+    else:
+        ext = ConvFeatureExtractor(conv_layers_spec=CONV_SPEC, in_channels=1)
     model = JEPA(feature_extractor=ext, transformer_encoder_cfg=TransformerEncoderCFG.create(),
                  transformer_encoder_layers_cfg=TransformerLayerCFG.create(), transformer_decoder_cfg=TransformerEncoderCFG.create(),
                  transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384), lr=4e-4, adam_betas=(0.9, 0.98),
@@ -228,7 +232,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips-per-gpu", type=int, default=256)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="2s-bf16",
-                    help="2s-bf16 = the headline metric (BASELINE config 2/3); 4s-fp8 = BASELINE config 5 (400 tokens, MX fp8 forward GEMMs)")
+                    help="2s-bf16 = the headline metric (BASELINE config 2/3); 4s-fp8 = BASELINE config 5 (400 tokens, MX fp8 forward GEMMs); "
+                         "2s-nat = BASELINE config 4 (device-side scene augmentation + 2-channel front-end)")
     ap.add_argument("--dense-steps", type=int, default=5, help="extra timed steps with the dense (non-ragged) shapes; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -245,14 +250,19 @@ def main():
     S = 8
     if args.clips_per_gpu % S:
         raise SystemExit("--clips-per-gpu must be a multiple of 8 (8 crops per source audio)")
-    seconds, fp8 = WORKLOADS[args.workload]
-    model = build_model(device, seed=42, seconds=seconds)          # same init on every rank (+ broadcast from rank 0 in StepRunner)
+    seconds, fp8, nat = WORKLOADS[args.workload]
+    model = build_model(device, seed=42, seconds=seconds, nat=nat)  # same init on every rank (+ broadcast from rank 0 in StepRunner)
     model._ensure_engine().fp8 = fp8
     model.trainer.max_steps = 375000
     masker = TimeInverseBlockMasker(target_masks_per_context=4, context_mask_prob=0.65, context_mask_length=10, target_prob=0.25,
-                                    target_length=10, ratio_cutoff=0.1)      # configs/masker/AudioSet.yaml
-    source = SyntheticAudioSource(masker, batch_size=args.clips_per_gpu // S, samples_per_audio=S, n_tokens=model.total_patches,
-                                  seed=42 + rank, n_mask_sets=64, device=device)      # masks pre-generated for 64 steps and cycled
+                                    target_length=10, ratio_cutoff=0.1, channel_based_masking=nat, channel_major=nat)   # configs/masker/AudioSet.yaml
+    src_kw = dict(batch_size=args.clips_per_gpu // S, samples_per_audio=S, n_tokens=model.total_patches, seed=42 + rank, n_mask_sets=64,
+                  device=device)                                                      # masks pre-generated for 64 steps and cycled
+    if nat:
+        from wavjepa_amd.data import NatSceneSource
+        source = NatSceneSource(masker, **src_kw)          # scene generation runs inside the timed step (next_batch)
+    else:
+        source = SyntheticAudioSource(masker, **src_kw)
     runner = StepRunner(model, gradient_clip_val=5.0)
 
     def sync():
@@ -354,7 +364,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"WavJEPA-base JEPA pre-training step, {seconds} s @16 kHz white-noise clips ({model.target_length} samples -> "
                                    f"{model.total_patches} tokens), {args.clips_per_gpu} clips per GPU ({args.clips_per_gpu // 8} sources x 8 crops), "
-                                   "AudioSet masker, random-init weights" + (", MX fp8 forward GEMMs (BASELINE config 5)" if fp8 else ""),
+                                   "AudioSet masker, random-init weights" + (", MX fp8 forward GEMMs (BASELINE config 5)" if fp8 else "")
+                                   + (", binaural scenes generated on the device inside the step (source RIR + 2 noise RIRs of 0.5 s, segmental-SNR mix) "
+                                      "and a 2-channel ConvChannelFeatureExtractor front-end (BASELINE config 4)" if nat else ""),
                        "workload_name": args.workload,
                        "global_batch": args.clips_per_gpu * world, "seq_len": model.total_patches, "parallelism": f"dp{world}",
                        # student / predictor run on their visible tokens only unless WJ_RAGGED=0 (same loss and gradients:
@@ -366,7 +378,7 @@ def main():
             "model_tflops_per_gpu": None if executed_gflop is None else round(executed_gflop / (elapsed / args.steps) / 1000, 1),
             # dense model FLOPs exactly as the reference computes them (283.7 GFLOP per clip and step), independent
             # of the rows the ragged execution does not compute -- the rate a dense-shape implementation would need to keep up
-            "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1) if seconds < 3 else None,
+            "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1) if seconds < 3 and not nat else None,
             # the same step computed with the reference's dense shapes (WJ_RAGGED=0 equivalent), this run
             "dense_ms_per_step": None if dense_ms is None else round(dense_ms, 2),
             "dense_clips_per_s": None if dense_ms is None else round(args.clips_per_gpu * world / (dense_ms / 1000), 1),

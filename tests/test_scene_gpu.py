@@ -139,3 +139,38 @@ def test_snr_mix_vs_oracle_and_reproducible():
     assert err(out, ref) < TOL
     assert torch.equal(out, scene.add_noise(cu(s), cu(n), cu(snr), cu(start), cu(length)))
     assert torch.equal(out[4].cpu(), torch.from_numpy(s[4]))              # empty window: source untouched
+
+
+def test_nat_workload_scene_front_end_feeds_two_channel_step():
+    """BASELINE config 4 wired end to end: `NatSceneSource` builds binaural scenes with the scene kernels (source RIR + noise RIRs +
+    SNR mix), the crops go through the 2-channel `ConvChannelFeatureExtractor` model and one optimisation step runs; the scene the
+    source produced equals the oracle's, and `bench.py --workload 2s-nat` runs as a child process."""
+    import json
+    import subprocess
+    import sys
+    from wavjepa_amd.data import NatSceneSource
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    masker = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True, channel_major=True)
+    src = NatSceneSource(masker, batch_size=2, samples_per_audio=2, n_tokens=400, seed=3, n_mask_sets=1, device=dev(), seconds=1.0)
+    state = src.gen.get_state()
+    audio, ctx, tgt, vis = src.next_batch()
+    assert audio.shape == (2, 2, 16000) and ctx.shape == (2, 2, 400) and bool(torch.isfinite(audio).all())
+    src.gen.set_state(state)                      # replay the draws of next_batch() for the oracle
+    g = src.gen
+    s = torch.randn(2, 16000, generator=g, device=dev())
+    n = torch.randn(2, 16000, generator=g, device=dev())
+    snr = torch.rand(2, generator=g, device=dev()) * 35.0 + 5.0
+    length = torch.randint(4000, 16000, (2,), generator=g, device=dev())
+    start = ((16000 - length).float() * torch.rand(2, generator=g, device=dev())).long()
+    conv = S.convolve_with_rir(s.cpu().numpy(), src.source_rir.cpu().numpy())
+    agg = S.aggregate_noise(src.noise_rirs.cpu().numpy(), n.cpu().numpy())
+    ref = S.add_noise(conv, agg, snr.cpu().numpy(), start.cpu().numpy(), length.cpu().numpy())
+    assert err(audio, ref) < TOL
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "2s-nat", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16",
+           "--dense-steps", "0", "--no-cpu-baseline", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["workload_name"] == "2s-nat" and line["config"]["seq_len"] == 400 and line["value"] > 0
+    assert np.isfinite(line["final_loss"])
