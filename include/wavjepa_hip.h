@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 8
+#define WJ_ABI_VERSION 9
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -163,11 +163,12 @@ int wj_layernorm_fwd(const wj_ln_fwd_args*, void* stream);
 
 /* Backward of the above.  ds = d(x + r) = LN-backward(dy);  dgamma/dbeta (and dbias = column sums of bf16(ds), the
  * bias gradient of the Linear that produced r) are ACCUMULATED with atomics into f32 buffers.
- *   dy: f32 [M][D] (+ optional second addend dy2 f32);  outputs ds_f32 / ds_bf16 optional;
+ *   dy: f32 [M][D] (+ optional second addend dy2: f32, or bf16 with dy2_is_bf16 -- the grad_input a bf16 linear returns, added to the
+ *   fp32 residual gradient here instead of by a read-modify-write GEMM epilogue);  outputs ds_f32 (may alias dy) / ds_bf16 optional;
  *   ds_bf16 row m is written at row (m / out_valid) * out_seg + (m % out_valid) when out_seg > 0. */
 typedef struct {
     const float* dy;
-    const float* dy2;
+    const void* dy2;
     const void* x;
     const void* r;
     const float* gamma;
@@ -185,6 +186,7 @@ typedef struct {
     int32_t in_seg, in_valid;
     int32_t out_seg, out_valid;
     int32_t chan;     /* S > 1: x (in_seg) and ds_bf16 (out_seg) buffers are channel-major, see wj_ln_fwd_args.in_chan */
+    int32_t dy2_is_bf16;
 } wj_ln_bwd_args;
 int wj_layernorm_bwd(const wj_ln_bwd_args*, void* stream);
 

@@ -210,7 +210,14 @@ __global__ __launch_bounds__(BWD_THREADS) void ln_bwd_kernel(wj_ln_bwd_args a) {
                         sx += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
                     }
                     f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + (long)m * D + col);
-                    if (a.dy2) d += *reinterpret_cast<const f32x4*>(a.dy2 + (long)m * D + col);
+                    if (a.dy2) {
+                        if (a.dy2_is_bf16) {
+                            const bf16x4 e2 = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.dy2 + (long)m * D + col);
+                            d += f32x4{bf2f(e2[0]), bf2f(e2[1]), bf2f(e2[2]), bf2f(e2[3])};
+                        } else {
+                            d += *reinterpret_cast<const f32x4*>((const float*)a.dy2 + (long)m * D + col);
+                        }
+                    }
                     xh[u][j] = sx;
                     dy[u][j] = d;
                 }

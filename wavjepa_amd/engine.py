@@ -496,6 +496,7 @@ class JepaEngine:
             self.bw[tag] = dict(
                 dy=_empty(m, d, dtype=f32, device=dev), ds=_empty(m, d, dtype=f32, device=dev),
                 dx1=_empty(m, d, dtype=f32, device=dev), do=_empty(m, d, dtype=bf, device=dev),
+                dgb=_empty(m, d, dtype=bf, device=dev), dxb=_empty(m, d, dtype=bf, device=dev),   # bf16 grad_input of linear1 / in_proj
                 dsb2=[_empty(m, d, dtype=bf, device=dev) for _ in range(nbuf)],
                 dsb1=[_empty(m, d, dtype=bf, device=dev) for _ in range(nbuf)],
                 dh=[_empty(m, 4 * d, dtype=bf, device=dev) for _ in range(nbuf)],
@@ -601,11 +602,16 @@ class JepaEngine:
             ev.record(self.side)
             torch.cuda.current_stream().wait_event(ev)
 
-    def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dx_out: torch.Tensor,
-                   M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int,
+    def _layer_bwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, dy: torch.Tensor, dyb: Optional[torch.Tensor],
+                   dx_out: torch.Tensor, M: int, D: int, H: int, B: int, mask: Optional[torch.Tensor], bw: dict, parity: int,
                    seq: Optional[Tuple[torch.Tensor, int]] = None,
-                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, flush: bool = True) -> bool:
-        """dy = d(x2) fp32 -> dx_out = d(x_in) fp32; parameter gradients accumulated into the flat gradient buffer.
+                   sub: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None, flush: bool = True, bottom: bool = False):
+        """d(x2) = dy (fp32) + dyb (bf16 or None) -> d(x_in), returned as (fp32 part, bf16 part or None, flushed); parameter gradients
+        accumulated into the flat gradient buffer.
+        The grad_input of linear1 and in_proj is what a bf16 linear returns under autocast -- a bf16 tensor (`dgb` / `dxb`) -- and the
+        LayerNorm backward that consumes the sum adds it to the fp32 residual gradient on its way in (`dy2`): 2 + 2 bytes per element
+        instead of the 4 + 4 of a read-modify-write fp32 GEMM epilogue.  Only the `bottom` layer of a stack folds the two into one
+        fp32 tensor (dx_out), for the consumers below the stack.
         The four weight-gradient GEMMs only need (dY, X) and nothing downstream needs them before the optimiser: they are queued
         and go out as one grouped launch on the side stream (with `flush`; `parity` = this layer's buffer slot) while the main
         stream continues the dgrad chain.  Returns True when the queue was flushed (the queued layers' gradients are then final in
@@ -618,15 +624,16 @@ class JepaEngine:
         if sub is not None:              # dy holds the sub-rows only; everything up to the attention works on them
             M = sub[2]
             x_ln1, o_in = self.tail_x, self.tail_o
-        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, ds_f32=ds, ds_bf16=dsb2, dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2,
-                          workspace=self.red_ws)
+        dgb, dxb = bw["dgb"], bw["dxb"]
+        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, dy2=dyb, dy2_is_bf16=dyb is not None, ds_f32=ds, ds_bf16=dsb2,
+                          dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2, workspace=self.red_ws)
         ops.gemm(dsb2, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
                  colsum=w.gb1)           # linear1.bias gradient = column sums of dh, fused into the producing epilogue
 
         bw["pending"] += [(dsb2, a.g, w.gw2, D, 4 * D, M), (dh, a.x1b, w.gw1, 4 * D, D, M)]
-        ops.gemm(dh, w.w1, dx1, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds)
-        ops.layernorm_bwd(dx1, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, ds_f32=ds, ds_bf16=dsb1, dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo,
-                          workspace=self.red_ws)
+        ops.gemm(dh, w.w1, dgb, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1)
+        ops.layernorm_bwd(ds, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, dy2=dgb, dy2_is_bf16=True, ds_f32=ds, ds_bf16=dsb1,
+                          dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo, workspace=self.red_ws)      # ds updated in place
         ds_all = ds
         if sub is None:
             ops.gemm(dsb1, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
@@ -654,8 +661,11 @@ class JepaEngine:
                         bw["done"][sl].record(self.side)
                         bw["used"][sl] = True
             self._on_side(wgrads)
-        ops.gemm(dqkv, w.wqkv, dx_out, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds_all)
-        return flush
+        if bottom:
+            ops.gemm(dqkv, w.wqkv, dx_out, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds_all)
+            return dx_out, None, flush
+        ops.gemm(dqkv, w.wqkv, dxb, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1)
+        return ds_all, dxb, flush
 
     # ------------------------------------------------------------------------------------------------ front-end
     def _frontend(self, audio: torch.Tensor) -> None:
@@ -847,11 +857,11 @@ class JepaEngine:
         last = self.dec_acts[-1]
         ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("decoder.norm.weight"), self.dec_fm, self.dec_fr, M=Mo, D=Dd, ds_f32=bw["dy"],
                           dgamma=f.gptr("decoder.norm.weight"), dbeta=f.gptr("decoder.norm.bias"), workspace=self.red_ws)
-        dy = bw["dy"]
+        dy, dyb = bw["dy"], None
         for i in range(c.l_dec - 1, -1, -1):
             x_in, xb_in = (self.dec_in, self.dec_in_b) if i == 0 else (self.dec_acts[i - 1].x2, self.dec_acts[i - 1].x2b)
-            self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dy, Md, Dd, c.h_dec, N * G, plan.vis_u8, bw, i % bw["nbuf"], dseq,
-                            sub=self.tail if (rag and i == c.l_dec - 1) else None)
+            dy, dyb, _ = self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dyb, bw["dy"], Md, Dd, c.h_dec, N * G, plan.vis_u8,
+                                         bw, i % bw["nbuf"], dseq, sub=self.tail if (rag and i == c.l_dec - 1) else None, bottom=i == 0)
         n_ctx = plan.n_ctx
         ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
                                       rowmap=plan.dec_map if rag else None)
@@ -869,15 +879,16 @@ class JepaEngine:
         last = self.enc_acts[-1]
         ops.layernorm_bwd(bw["dx1"], last.x2, f.ptr32("encoder.norm.weight"), self.enc_fm, self.enc_fr, M=Me, D=De, ds_f32=bw["dy"],
                           dgamma=f.gptr("encoder.norm.weight"), dbeta=f.gptr("encoder.norm.bias"), workspace=self.red_ws)
-        dy = bw["dy"]
+        dy, dyb = bw["dy"], None
         enc_ready = set()
         for i in range(c.l_enc - 1, -1, -1):
             first = (self.enc_in, self.enc_in_b) if rag else (self.lf, self.lf_b)
             x_in, xb_in = first if i == 0 else (self.enc_acts[i - 1].x2, self.enc_acts[i - 1].x2b)
             # the weight gradients of two layers share a grouped launch: a layer's section of the gradient buffer is final (and its
             # all-reduce bucket may go) once the launch that carries it has been queued
-            done = self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dy, Me, De, c.h_enc, N, plan.ctx_u8, bw, i % bw["nbuf"],
-                                   eseq, flush=(c.l_enc - 1 - i) % bw["group"] == bw["group"] - 1 or i == 0)
+            dy, dyb, done = self._layer_bwd(self.enc_layers[i], self.enc_acts[i], x_in, xb_in, dy, dyb, bw["dy"], Me, De, c.h_enc, N, plan.ctx_u8,
+                                            bw, i % bw["nbuf"], eseq, flush=(c.l_enc - 1 - i) % bw["group"] == bw["group"] - 1 or i == 0,
+                                            bottom=i == 0)
             if done:
                 for j in range(min(c.l_enc - 1, i + bw["group"] - 1), i - 1, -1):
                     if j not in enc_ready:

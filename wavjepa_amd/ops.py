@@ -153,8 +153,8 @@ def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, 
 def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
                   ds_f32: Ptr = None, ds_bf16: Ptr = None, dgamma: Ptr = None, dbeta: Ptr = None, dbias: Ptr = None,
                   x_is_bf16: bool = False, in_seg: int = 0, in_valid: int = 0, out_seg: int = 0, out_valid: int = 0,
-                  chan: int = 0, workspace: Ptr = None, stream: Optional[int] = None) -> None:
-    _run("wj_layernorm_bwd", "wj_ln_bwd_args", stream, dy=_p(dy), dy2=_p(dy2), x=_p(x), r=_p(r), gamma=_p(gamma),
+                  chan: int = 0, workspace: Ptr = None, dy2_is_bf16: bool = False, stream: Optional[int] = None) -> None:
+    _run("wj_layernorm_bwd", "wj_ln_bwd_args", stream, dy=_p(dy), dy2=_p(dy2), dy2_is_bf16=int(dy2_is_bf16), x=_p(x), r=_p(r), gamma=_p(gamma),
          mean=_p(mean), rstd=_p(rstd), ds_f32=_p(ds_f32), ds_bf16=_p(ds_bf16), dgamma=_p(dgamma), dbeta=_p(dbeta),
          dbias=_p(dbias), workspace=_p(workspace), M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, out_seg=out_seg,
          out_valid=out_valid, chan=chan)
