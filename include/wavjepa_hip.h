@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 9
+#define WJ_ABI_VERSION 10
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -560,6 +560,42 @@ typedef struct {
     int32_t B, C, T;
 } wj_snr_mix_args;
 int wj_snr_mix(const wj_snr_mix_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Denoiser stage (wavjepa/denoiser.py).
+ *
+ * wj_resample_fir: polyphase FIR resampling with a caller-supplied kernel table, as torchaudio.functional.resample applies its
+ *   windowed-sinc kernel (denoiser.py:29-42: 32 kHz -> 16 kHz, kaiser window, lowpass_filter_width 64; WebAudioDataModule.py:50-60):
+ *       xpad = [0] * width + x + [0] * (width + orig);   y[b][i * nw + p] = sum_{k < taps} kernel[p][k] * xpad[b][i * orig + k]
+ *   for every i * nw + p < L_out (the caller passes L_out = ceil(new * L_in / orig); nw = new / gcd, orig = orig / gcd,
+ *   taps = 2 * width + orig).  x f32 [B][L_in], kernel f32 [nw][taps], y f32 [B][L_out].
+ *
+ * wj_mse_groups: G prediction sets against one target tensor (denoiser.py:350-355):
+ *       loss[1 + g] = mean((preds[g] - targets)^2);  loss[0] = sum_g w[g] * loss[1 + g]
+ *       dpreds[g] = gscale[0] * w[g] * 2 (preds[g] - targets) / n          (optional; gscale NULL = 1)
+ *   preds / dpreds f32 [G][n], targets f32 [n], w f32 [G] (device), G <= 4.  workspace: wj_workspace_bytes("wj_mse_groups").
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const float* x;
+    const float* kernel;
+    float* y;
+    int32_t B, L_in, L_out;
+    int32_t orig, nw, width, taps;
+} wj_resample_args;
+int wj_resample_fir(const wj_resample_args*, void* stream);
+
+typedef struct {
+    const float* preds;
+    const float* targets;
+    const float* w;
+    const float* gscale;
+    float* loss;
+    float* dpreds;
+    float* workspace;
+    int64_t n;
+    int32_t G;
+} wj_mse_groups_args;
+int wj_mse_groups(const wj_mse_groups_args*, void* stream);
 
 #ifdef __cplusplus
 }

@@ -447,8 +447,51 @@ def gen_scene():
     np.savez_compressed(os.path.join(HERE, "scene.npz"), **fx)
 
 
+def gen_denoiser():
+    """Denoiser stage: the reference's own wavjepa/denoiser.py `Denoiser.forward` (fp32, alpha 0.3) with a small frozen
+    reference JEPA as teacher -- losses, contextual features, every parameter-gradient norm and three full gradients.
+    (torchaudio / webdataset are import-time stand-ins only; nothing numeric comes from them on this path.)"""
+    RI.install_stubs()
+    import wavjepa.denoiser as ref_den
+    torch.manual_seed(77)
+    spec = list(TINY_SPEC)
+    teacher = build_ref(spec, 64, 2, 2, 32, 1, 2, top_k=2)
+    ext = R.ConvFeatureExtractor(conv_layers_spec=list(spec), in_channels=1)
+    den = ref_den.Denoiser(feature_extractor=ext, transformer_encoder_layers_cfg=R.TransformerLayerCFG.create(d_model=64, nhead=2),
+                           transformer_encoder_cfg=R.TransformerEncoderCFG.create(num_layers=2), alpha=0.3, process_audio_seconds=2.01)
+    with torch.no_grad():
+        for n, p in list(den.named_parameters()) + list(teacher.named_parameters()):
+            if n.endswith("bias"):
+                p.add_(0.02 * torch.randn_like(p))
+            elif "norm" in n and n.endswith("weight") or n.endswith("cnn.0.2.weight"):
+                p.add_(0.1 * torch.randn_like(p))
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval()
+    den.teacher = teacher
+    N = 2
+    clean = torch.randn(N, 1, 32159)
+    generated = clean + 0.5 * torch.randn(N, 1, 32159)
+    fx = {f"sd::{k}": v for k, v in sd_numpy(den).items() if not k.startswith("teacher.")}
+    fx.update({f"tsd::{k}": v for k, v in sd_numpy(teacher).items()})
+    fx.update(clean=clean.numpy(), generated=generated.numpy(), alpha=np.float64(0.3))
+    den.train()
+    out = den(generated, clean)
+    out["loss"].backward()
+    for k in ("loss", "loss_clean", "loss_denoise_dereverb"):
+        fx[f"out::{k}"] = out[k].detach().float().numpy()
+    gn = {n: float(p.grad.norm()) for n, p in den.named_parameters() if p.grad is not None and not n.startswith("teacher.")}
+    fx["grad_names"] = np.array(list(gn.keys()))
+    fx["grad_norms"] = np.array(list(gn.values()), dtype=np.float64)
+    fx["grad::extract_audio.cnn.0.0.weight"] = den.extract_audio.cnn[0][0].weight.grad.numpy()
+    fx["grad::encoder.layers.1.linear1.weight"] = den.encoder.layers[1].linear1.weight.grad.numpy()
+    fx["grad::encoder.norm.weight"] = den.encoder.norm.weight.grad.numpy()
+    fx["state_dict_names"] = np.array([k for k in den.state_dict().keys() if not k.startswith("teacher.")])
+    np.savez_compressed(os.path.join(HERE, "denoiser.npz"), **fx)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -464,6 +507,8 @@ if __name__ == "__main__":
         gen_channel(masks)
     if "scene" in which:
         gen_scene()
+    if "denoiser" in which:
+        gen_denoiser()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

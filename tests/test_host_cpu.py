@@ -74,6 +74,17 @@ def test_product_path_fails_loudly_without_gpu():
         scene.convolve_with_rir(torch.zeros(2, 100), torch.zeros(2, 1, 10))
     with pytest.raises(RuntimeError):
         scene.add_noise(torch.zeros(2, 1, 100), torch.zeros(2, 1, 100), torch.zeros(2), torch.zeros(2), torch.zeros(2))
+    from wavjepa_amd.denoiser import Denoiser
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.resample import resample
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    with pytest.raises(RuntimeError):
+        resample(torch.zeros(1, 1, 1000), 16000)
+    den = Denoiser(ConvFeatureExtractor(conv_layers_spec=[(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)], in_channels=1),
+                   TransformerLayerCFG.create(d_model=64, nhead=2), TransformerEncoderCFG.create(num_layers=1))
+    den._set_teacher(m)
+    with pytest.raises(RuntimeError):
+        den(torch.zeros(1, 1, den.target_length), torch.zeros(1, 1, den.target_length))
 
 
 class Pinned:

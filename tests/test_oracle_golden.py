@@ -293,3 +293,59 @@ def test_scene_oracle_matches_reference_fixture(golden_dir):
     b, c, t = 1, 1, 4321
     direct = sum(float(src[b, t - k]) * float(srir[b, c, k]) for k in range(min(t + 1, srir.shape[-1])))
     assert abs(S.convolve_with_rir(src, srir)[b, c, t] - direct) < 1e-9 * max(1.0, abs(direct))
+
+
+def test_denoiser_oracle_matches_reference_fixture(golden_dir):
+    """oracle/denoiser_oracle.py against the reference's own Denoiser.forward (fixture denoiser.npz: fp32, alpha 0.3, a small
+    frozen reference JEPA as teacher): the three losses to 2e-5 relative, every parameter-gradient norm to 2e-4, three full
+    gradients to 2e-4 relative L2; and the state_dict layout of wavjepa_amd.denoiser.Denoiser name by name."""
+    from oracle import denoiser_oracle as DN
+    fx = dict(np.load(os.path.join(golden_dir, "denoiser.npz")))
+    P = {k[4:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("sd::")}
+    PT = {k[5:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("tsd::")}
+    spec = [(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)]
+    names = [n for n in fx["grad_names"]]
+    for n in names:
+        P[n].requires_grad_(True)
+    out = DN.denoiser_forward(P, PT, torch.from_numpy(fx["generated"]), torch.from_numpy(fx["clean"]), alpha=float(fx["alpha"]), spec=spec,
+                              enc_heads=2, mode="fp32")
+    for k in ("loss", "loss_clean", "loss_denoise_dereverb"):
+        ref = float(fx[f"out::{k}"])
+        assert abs(float(out[k]) - ref) < 2e-5 * abs(ref), (k, float(out[k]), ref)
+    out["loss"].backward()
+    for n, gn in zip(names, fx["grad_norms"]):
+        assert abs(float(P[n].grad.norm()) - gn) < 2e-4 * gn + 1e-9, (n, float(P[n].grad.norm()), gn)
+    for k in ("extract_audio.cnn.0.0.weight", "encoder.layers.1.linear1.weight", "encoder.norm.weight"):
+        g, r = P[k].grad.double(), torch.from_numpy(fx[f"grad::{k}"]).double()
+        assert float((g - r).norm() / r.norm()) < 2e-4, k
+    from wavjepa_amd.denoiser import Denoiser
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    m = Denoiser(ConvFeatureExtractor(conv_layers_spec=spec, in_channels=1), TransformerLayerCFG.create(d_model=64, nhead=2),
+                 TransformerEncoderCFG.create(num_layers=2), alpha=0.3)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sorted(mine) == sorted(str(n) for n in fx["state_dict_names"])
+    for k, shp in mine.items():
+        assert shp == tuple(fx[f"sd::{k}"].shape), k
+
+
+def test_resample_oracle_known_answers():
+    """oracle/resample_oracle.py (torchaudio's published kaiser-sinc resampling, restated): properties that follow from the
+    definition at the reference's call site (32 kHz -> 16 kHz, width 64, rolloff 0.9476, beta 14.77), and the host-side kernel
+    table of the product path against the oracle's loop-built one."""
+    from oracle import resample_oracle as R
+    from wavjepa_amd.resample import KAISER_BEST, sinc_resample_kernel
+    k, width, orig, new = R.kernel(32000, 16000, 64, KAISER_BEST["rolloff"], "sinc_interp_kaiser", KAISER_BEST["beta"])
+    assert (k.shape, width, orig, new) == ((1, 274), 136, 2, 1)
+    k2, w2, o2, n2 = sinc_resample_kernel(32000, 16000, resampling_method="sinc_interp_kaiser", **KAISER_BEST)
+    assert (w2, o2, n2) == (width, orig, new) and np.abs(k - k2).max() < 1e-7
+    assert abs(k.sum() - 1.0) < 1e-6                                                  # unit DC gain
+    t32, t16 = np.arange(32000) / 32000.0, np.arange(16000) / 16000.0
+    y = R.resample(np.sin(2 * np.pi * 1000 * t32)[None], 32000, 16000)[0]
+    assert y.shape == (16000,) and np.abs(y[300:-300] - np.sin(2 * np.pi * 1000 * t16)[300:-300]).max() < 1e-8   # in-band: unchanged
+    y = R.resample(np.sin(2 * np.pi * 12000 * t32)[None], 32000, 16000)[0]
+    assert np.abs(y[300:-300]).max() < 1e-6                                           # above the new Nyquist: rejected
+    assert R.resample(np.zeros((2, 3, 1001)), 32000, 16000).shape == (2, 3, 501)      # ceil(new * L / orig)
+    k3, w3, o3, n3 = sinc_resample_kernel(44100, 16000)                               # hann default, non-trivial ratio
+    kk, *_ = R.kernel(44100, 16000)
+    assert k3.shape == (160, 2 * w3 + 441) and np.abs(kk - k3).max() < 1e-7

@@ -364,7 +364,8 @@ class JepaEngine:
         f = self.flat
         if force_cast or not f.bf16_fresh:
             ops.cast_f32_to_bf16(f.p32, f.p16, f.n)
-            ops.cast_f32_to_bf16(f.t32, f.t16, f.tn)
+            if f.tn > 0:
+                ops.cast_f32_to_bf16(f.t32, f.t16, f.tn)
             f.bf16_fresh = True
         if self.fp8:
             self._fp8_weights()
@@ -673,7 +674,7 @@ class JepaEngine:
         c, f, N, C, S = self.cfg, self.flat, self.N, self.C, self.S
         _, k0, s0 = c.conv_spec[0]
         taps = c.in_channels * k0
-        grad = torch.is_grad_enabled()
+        grad = torch.is_grad_enabled() and self.gn_yx is not None      # (an inference arena keeps no backward sums)
         audio_p = audio.data_ptr()
         for ch in range(S):                               # every stream: N mono clips (ConvFeatureExtractor: one stream, C_in channels)
             pre = self.stacks[min(ch, len(self.stacks) - 1)]
@@ -894,7 +895,18 @@ class JepaEngine:
                     if j not in enc_ready:
                         enc_ready.add(j)
                         ready(f"enc:{j}")
-        # dy = d(local_features) fp32 (zero on non-context rows).  The teacher branch is detached (jepa.py:408).
+        self._frontend_bwd(dy, rag, plan)
+        self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
+        for tag in ("enc", "dec"):
+            self.bw[tag]["used"] = [False] * self.bw[tag]["nbuf"]
+        if on_grads_ready is not None:
+            on_grads_ready("front")
+
+    def _frontend_bwd(self, dy: torch.Tensor, rag: bool, plan: Optional[MaskPlan]) -> None:
+        """dy = d(local_features) fp32 [M, d_enc] (packed context rows on a ragged step) -> gradients of the mapper, feature_norms
+        and the conv stack.  (JEPA: zero on non-context rows; the teacher branch is detached, jepa.py:408.)"""
+        c, f = self.cfg, self.flat
+        N, M, C, De = self.N, self.M, self.C, c.d_enc
         if rag:
             ops.unmask_rows_f32(dy, plan.inv, self.d_lf_b, M=M, D=De, src_is_f32=True, dst_is_bf16=True)
             if not self.has_mapper:
@@ -979,11 +991,6 @@ class JepaEngine:
                           L_out=self.L[0], P=self.P[0], audio_clip_stride=S * c.in_channels * c.n_samples if S > 1 else 0, **lists)
             if sparse:
                 ops.zero_rows(self.dpost_ptr[0] + c0 * self.P[0] * C * 2, rows0, n_rows=n0, row_bytes=C * 2)
-        self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
-        for tag in ("enc", "dec"):
-            self.bw[tag]["used"] = [False] * self.bw[tag]["nbuf"]
-        if on_grads_ready is not None:
-            on_grads_ready("front")
 
     def _conv_rows(self, plan: MaskPlan):
         """Device copies of conv_active_rows for this plan (cached on the plan: mask sets are reused by the data source).

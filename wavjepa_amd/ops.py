@@ -67,7 +67,7 @@ def workspace_bytes(fn: str, **dims) -> int:
     """Scratch bytes entry point `fn` needs for the given dimensions (fields of its argument struct), from the library."""
     struct_name = {"wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
                    "wj_conv0_gn_gelu_bwd": "wj_conv0_bwd_args", "wj_masked_mse": "wj_mse_args", "wj_grad_sumsq": "wj_sumsq_args",
-                   "wj_rir_convolve": "wj_rir_conv_args", "wj_snr_mix": "wj_snr_mix_args"}[fn]
+                   "wj_rir_convolve": "wj_rir_conv_args", "wj_snr_mix": "wj_snr_mix_args", "wj_mse_groups": "wj_mse_groups_args"}[fn]
     a = STRUCTS[struct_name]()
     for k, v in dims.items():
         setattr(a, k, v)
@@ -318,3 +318,18 @@ def snr_mix(source: Ptr, noise: Ptr, out: Ptr, snr: Ptr, start: Ptr, length: Ptr
     """out = source + a * noise with the segmental-SNR gain a of generate_scenes_batch.py:108-150."""
     _run("wj_snr_mix", "wj_snr_mix_args", stream, source=_p(source), noise=_p(noise), out=_p(out), snr=_p(snr), start=_p(start),
          length=_p(length), workspace=_p(workspace), B=B, C=C, T=T)
+
+
+# ---------------------------------------------------------------------------------------------------------- denoiser stage
+def resample_fir(x: Ptr, kernel: Ptr, y: Ptr, *, B: int, L_in: int, L_out: int, orig: int, nw: int, width: int,
+                 stream: Optional[int] = None) -> None:
+    """Polyphase FIR resampling with a [nw][2 * width + orig] kernel table (torchaudio.functional.resample's application step)."""
+    _run("wj_resample_fir", "wj_resample_args", stream, x=_p(x), kernel=_p(kernel), y=_p(y), B=B, L_in=L_in, L_out=L_out, orig=orig, nw=nw,
+         width=width, taps=2 * width + orig)
+
+
+def mse_groups(preds: Ptr, targets: Ptr, w: Ptr, loss: Ptr, workspace: Ptr, *, n: int, G: int, dpreds: Ptr = None, gscale: Ptr = None,
+               stream: Optional[int] = None) -> None:
+    """loss[0] = sum_g w[g] * mean((preds[g] - targets)^2), loss[1 + g] the per-set means; optional gradient (denoiser.py:350-355)."""
+    _run("wj_mse_groups", "wj_mse_groups_args", stream, preds=_p(preds), targets=_p(targets), w=_p(w), gscale=_p(gscale), loss=_p(loss),
+         dpreds=_p(dpreds), workspace=_p(workspace), n=n, G=G)

@@ -69,10 +69,11 @@ class FlatParams:
                 p.data = view
         # the student-encoder slice must mirror the teacher layout 1:1 (single-kernel EMA over contiguous memory)
         enc = [s for s in self.slots if s.name.startswith("encoder.")]
-        assert len(enc) == len(self.tslots), "student encoder / teacher parameter lists differ"
         self.enc_offset = enc[0].offset
-        for s, t in zip(enc, self.tslots):
-            assert "teacher_" + s.name == t.name and s.offset - self.enc_offset == t.offset and s.numel == t.numel
+        if self.tslots:                  # (the denoiser stage has no EMA copy inside the module: its teacher is a frozen JEPA)
+            assert len(enc) == len(self.tslots), "student encoder / teacher parameter lists differ"
+            for s, t in zip(enc, self.tslots):
+                assert "teacher_" + s.name == t.name and s.offset - self.enc_offset == t.offset and s.numel == t.numel
         self.enc_numel = self.tn
         self.bf16_fresh = False
 
@@ -96,9 +97,12 @@ class FlatParams:
         """True while the module's parameters still alias the flat buffers (e.g. not after .to()/.cuda())."""
         params = dict(module.named_parameters())
         s = self.slots[-1]
+        if params[s.name].data_ptr() != self.p32.data_ptr() + 4 * s.offset:
+            return False
+        if not self.tslots:
+            return True
         t = self.tslots[-1]
-        return (params[s.name].data_ptr() == self.p32.data_ptr() + 4 * s.offset and
-                params[t.name].data_ptr() == self.t32.data_ptr() + 4 * t.offset)
+        return params[t.name].data_ptr() == self.t32.data_ptr() + 4 * t.offset
 
     def attach_grads(self) -> None:
         """(Re-)expose the flat gradient buffer as every parameter's .grad (zero_grad(set_to_none) drops them)."""

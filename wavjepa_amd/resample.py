@@ -1,0 +1,74 @@
+"""Kaiser-windowed sinc resampling on the GPU (the reference's `resample`, wavjepa/denoiser.py:29-42 and
+data_modules/WebAudioDataModule.py:50-60: torchaudio.functional.resample(audio, 32000, 16000, lowpass_filter_width=64,
+rolloff=0.9475937167399596, resampling_method="sinc_interp_kaiser", beta=14.769656459379492)).
+
+torchaudio is a third-party dependency of the reference that is neither vendored there nor installed here; its published
+algorithm has two steps, restated below: (1) a [new/gcd][2 * width + orig/gcd] table of windowed-sinc taps
+(`_get_sinc_resample_kernel`), built here on the host in float64 and rounded to float32 once per (orig, new) pair; (2) a strided
+convolution of the zero-padded signal with that table, interleaving the phases and cutting to ceil(new * L / orig) samples
+(`_apply_sinc_resample_kernel`) -- the HIP kernel `wj_resample_fir`.  GPU only: CPU tensors raise.
+"""
+import math
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from . import ops
+
+KAISER_BEST = dict(lowpass_filter_width=64, rolloff=0.9475937167399596, beta=14.769656459379492)
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99,
+                         resampling_method: str = "sinc_interp_hann", beta=None):
+    """-> (kernel float32 [new/gcd][2 * width + orig/gcd], width, orig/gcd, new/gcd)"""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx
+    t = np.clip(t * base_freq, -lowpass_filter_width, lowpass_filter_width)
+    if resampling_method == "sinc_interp_hann":
+        window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    elif resampling_method == "sinc_interp_kaiser":
+        b = 14.769656459379492 if beta is None else float(beta)
+        window = np.i0(b * np.sqrt(1 - (t / lowpass_filter_width) ** 2)) / np.i0(b)
+    else:
+        raise ValueError(f"Invalid resampling method: {resampling_method}")
+    t = t * math.pi
+    scale = base_freq / orig
+    with np.errstate(invalid="ignore", divide="ignore"):
+        kern = np.where(t == 0, 1.0, np.sin(t) / t)
+    kern = kern * window * scale
+    return kern.astype(np.float32), width, orig, new
+
+
+@lru_cache(maxsize=8)
+def _kernel_on(device_index: int, orig_freq: int, new_freq: int, width_param: int, rolloff: float, method: str, beta):
+    kern, width, orig, new = sinc_resample_kernel(orig_freq, new_freq, width_param, rolloff, method, beta)
+    return torch.from_numpy(kern).to(torch.device("cuda", device_index)), width, orig, new
+
+
+def resample_waveform(waveform: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99,
+                      resampling_method: str = "sinc_interp_hann", beta=None) -> torch.Tensor:
+    """torchaudio.functional.resample semantics for [..., time] float tensors on the GPU."""
+    ops.require_gpu()
+    if not waveform.is_cuda:
+        raise ops._abi.WavJepaHipError(f"resampling runs on the GPU only: the waveform is on {waveform.device}")
+    if orig_freq == new_freq:
+        return waveform
+    kern, width, orig, new = _kernel_on(waveform.device.index or 0, int(orig_freq), int(new_freq), int(lowpass_filter_width), float(rolloff),
+                                        resampling_method, beta)
+    shape = waveform.shape
+    x = waveform.reshape(-1, shape[-1]).float().contiguous()
+    B, L = x.shape
+    L_out = int(math.ceil(new * L / orig))
+    y = torch.empty(B, L_out, device=x.device, dtype=torch.float32)
+    ops.resample_fir(x, kern, y, B=B, L_in=L, L_out=L_out, orig=orig, nw=new, width=width)
+    return y.view(shape[:-1] + (L_out,))
+
+
+def resample(audio: torch.Tensor, resample_sr: int, original_sr: int = 32000) -> torch.Tensor:
+    """reference wavjepa/denoiser.py:29-42 ("kaiser best")."""
+    return resample_waveform(audio, original_sr, resample_sr, resampling_method="sinc_interp_kaiser", **KAISER_BEST)

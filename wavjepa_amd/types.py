@@ -13,6 +13,8 @@ class ForwardReturn(TypedDict, total=False):
     loss: torch.Tensor
     preds: torch.Tensor
     targets: torch.Tensor
+    loss_clean: torch.Tensor                # denoiser stage (reference denoiser.py:357-361)
+    loss_denoise_dereverb: torch.Tensor
 
 
 class TransformerLayerCFG(TypedDict):
