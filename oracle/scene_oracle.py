@@ -69,3 +69,54 @@ def generate_scene(source_rir, noise_rirs, source, noise, real_noise_length, noi
     if noise is not None:
         return add_noise(source, noise, snr, noise_start_idx, real_noise_length, dtype)
     return source
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Evaluation-time twin: reference hear_api/heaRIR/scene_module/generate_scenes.py (per clip; 1-D source / noise)
+#   apply_fadein / apply_fadeout :11-33, add_noise :63-138 (= torchaudio.functional.add_noise), fade_noise :141-152,
+#   aggregate_noise :155-167, process_audio :170-191, generate_scene :194-203
+# ----------------------------------------------------------------------------------------------------------------------
+def fade(audio: np.ndarray, sr: int, duration: float, fade_in: bool) -> np.ndarray:
+    out = audio.astype(np.float64).copy()
+    n = int(duration * sr)
+    ramp = np.linspace(0.0, 1.0, n)
+    if fade_in:
+        out[:n] *= ramp
+    else:
+        out[out.shape[0] - n:] *= ramp[::-1]
+    return out
+
+
+def fade_noise(noise: np.ndarray, audio: np.ndarray, sr: int) -> np.ndarray:
+    if noise.shape[-1] > audio.shape[-1]:
+        return fade(noise[: audio.shape[-1]], sr, 0.2, False)
+    return fade(fade(noise, sr, 0.2, True), sr, 0.2, False)
+
+
+def add_noise_full(waveform: np.ndarray, noise: np.ndarray, snr, lengths=None) -> np.ndarray:
+    """[..., L] tensors; energies over the first `lengths` samples (all when None)."""
+    x, n = waveform.astype(np.float64), noise.astype(np.float64)
+    L = x.shape[-1]
+    if lengths is not None:
+        m = np.arange(L) < np.asarray(lengths)[..., None]
+        es, en = ((x * m) ** 2).sum(-1), ((n * m) ** 2).sum(-1)
+    else:
+        es, en = (x ** 2).sum(-1), (n ** 2).sum(-1)
+    scale = 10.0 ** ((10.0 * (np.log10(es) - np.log10(en)) - np.asarray(snr, dtype=np.float64)) / 20.0)
+    return x + scale[..., None] * n
+
+
+def hear_generate_scene(source_rir: np.ndarray, noise_rirs, source: np.ndarray, noise, snr: float, sr: int, rng=np.random):
+    """source 1-D, source_rir [C, L], noise_rirs list of [C, L], noise 1-D (or None with an empty noise_rirs) -> [C, T]"""
+    conv = convolve_with_rir(source[None], source_rir[None])[0]
+    if len(noise_rirs) == 0:
+        return conv
+    T = source.shape[-1]
+    nz = fade_noise(noise, source, sr)
+    agg = sum(convolve_with_rir(nz[None], r[None])[0] for r in noise_rirs)[:, :T]
+    if conv.shape[1] > agg.shape[1]:
+        start = rng.randint(0, T - agg.shape[1])
+        placed = np.zeros_like(conv)
+        placed[:, start:start + agg.shape[1]] = agg
+        agg = placed
+    return add_noise_full(conv, agg, np.full(conv.shape[0], snr))

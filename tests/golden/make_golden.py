@@ -490,8 +490,49 @@ def gen_denoiser():
     np.savez_compressed(os.path.join(HERE, "denoiser.npz"), **fx)
 
 
+def gen_hear_scene():
+    """Evaluation-time twin (reference hear_api/heaRIR/scene_module/generate_scenes.py), same fftconvolve stand-in as gen_scene."""
+    import importlib.util
+    RI.install_stubs()
+
+    def fftconvolve(x, y, mode="full"):
+        n = x.size(-1) + y.size(-1) - 1
+        return torch.fft.irfft(torch.fft.rfft(x, n=n) * torch.fft.rfft(y, n=n), n=n)
+
+    sys.modules["torchaudio"].functional.fftconvolve = fftconvolve
+    spec = importlib.util.spec_from_file_location("ref_hear_scene", os.path.join(RI.REFERENCE_ROOT, "hear_api", "heaRIR", "scene_module",
+                                                                                 "generate_scenes.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    g = torch.Generator().manual_seed(31)
+    sr, T, L = 16000, 9000, 800
+    src = torch.randn(T, generator=g)
+    noise_same = torch.randn(T, generator=g)
+    noise_long = torch.randn(T + 2500, generator=g)
+    noise_short = torch.randn(5000, generator=g)
+    srir = torch.randn(2, L, generator=g) * torch.exp(-torch.arange(L) / 90.0)
+    nrirs = [torch.randn(2, L, generator=g) * torch.exp(-torch.arange(L) / 140.0) for _ in range(2)]
+    fx = dict(source=src.numpy(), noise_same=noise_same.numpy(), noise_long=noise_long.numpy(), noise_short=noise_short.numpy(),
+              source_rir=srir.numpy(), noise_rir0=nrirs[0].numpy(), noise_rir1=nrirs[1].numpy(), sr=np.int64(sr))
+    fx["conv"] = ref.convolve_with_rir(src, srir).numpy()
+    fx["conv_1d_rir"] = ref.convolve_with_rir(src, srir[0]).numpy()
+    w, n2 = torch.randn(3, 4000, generator=g), torch.randn(3, 4000, generator=g)
+    snr3, len3 = torch.tensor([3.0, -2.0, 15.0]), torch.tensor([4000, 1000, 2500])
+    fx.update(mix_w=w.numpy(), mix_n=n2.numpy(), mix_snr=snr3.numpy(), mix_len=len3.numpy())
+    fx["mix_full"] = ref.add_noise(w, n2, snr3).numpy()
+    fx["mix_lengths"] = ref.add_noise(w, n2, snr3, len3).numpy()
+    fx["fade_long"] = ref.fade_noise(noise_long.clone(), src, sr).numpy()
+    fx["fade_short"] = ref.fade_noise(noise_short.clone(), src, sr).numpy()
+    fx["scene_same"] = ref.generate_scene(srir, nrirs, src.clone(), noise_same.clone(), 7.0, sr).numpy()
+    fx["scene_long"] = ref.generate_scene(srir, nrirs, src.clone(), noise_long.clone(), 0.0, sr).numpy()
+    np.random.seed(5)
+    fx["scene_short"] = ref.generate_scene(srir, nrirs, src.clone(), noise_short.clone(), 12.0, sr).numpy()
+    fx["scene_no_noise"] = ref.generate_scene(srir, [], src.clone(), None, 5.0, sr).numpy()
+    np.savez_compressed(os.path.join(HERE, "hear_scene.npz"), **fx)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -509,6 +550,8 @@ if __name__ == "__main__":
         gen_scene()
     if "denoiser" in which:
         gen_denoiser()
+    if "hear_scene" in which:
+        gen_hear_scene()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

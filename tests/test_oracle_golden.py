@@ -349,3 +349,65 @@ def test_resample_oracle_known_answers():
     k3, w3, o3, n3 = sinc_resample_kernel(44100, 16000)                               # hann default, non-trivial ratio
     kk, *_ = R.kernel(44100, 16000)
     assert k3.shape == (160, 2 * w3 + 441) and np.abs(kk - k3).max() < 1e-7
+
+
+def test_hear_scene_oracle_matches_reference_fixture(golden_dir):
+    """The evaluation-time twin (reference hear_api/heaRIR/scene_module/generate_scenes.py, fixture hear_scene.npz): per-clip RIR
+    convolution, torchaudio-style add_noise with and without lengths, the noise fades, and generate_scene for noise of equal /
+    greater / smaller length (the last with the reference's np.random placement replayed) and without noise."""
+    from oracle import scene_oracle as S
+    fx = dict(np.load(os.path.join(golden_dir, "hear_scene.npz")))
+    sr = int(fx["sr"])
+    src, srir, nr = fx["source"], fx["source_rir"], [fx["noise_rir0"], fx["noise_rir1"]]
+
+    def close(got, ref, tol=2e-5):
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() / np.sqrt((ref.astype(np.float64) ** 2).mean()) < tol
+
+    close(S.convolve_with_rir(src[None], srir[None])[0], fx["conv"])
+    close(S.convolve_with_rir(src[None], srir[None, :1])[0], fx["conv_1d_rir"])
+    close(S.add_noise_full(fx["mix_w"], fx["mix_n"], fx["mix_snr"]), fx["mix_full"])
+    close(S.add_noise_full(fx["mix_w"], fx["mix_n"], fx["mix_snr"], fx["mix_len"]), fx["mix_lengths"])
+    close(S.fade_noise(fx["noise_long"], src, sr), fx["fade_long"])
+    close(S.fade_noise(fx["noise_short"], src, sr), fx["fade_short"])
+    close(S.hear_generate_scene(srir, nr, src, fx["noise_same"], 7.0, sr), fx["scene_same"])
+    close(S.hear_generate_scene(srir, nr, src, fx["noise_long"], 0.0, sr), fx["scene_long"])
+    rng = np.random.RandomState(5)
+    close(S.hear_generate_scene(srir, nr, src, fx["noise_short"], 12.0, sr, rng=rng), fx["scene_short"])
+    close(S.hear_generate_scene(srir, [], src, None, 5.0, sr), fx["scene_no_noise"])
+
+
+def test_hear_scene_iterators_read_the_dataset_layout(tmp_path):
+    """SceneIterator / NoiseIterator (reference hear_api/heaRIR/iterators): JSON scene descriptions + .npy RIRs looked up by
+    basename, padded / cut to 2 s at 32 kHz; .wav noise clips as float32 [channels, samples]."""
+    import json
+    from scipy.io import wavfile
+    from hear_api.heaRIR.iterators import NoiseIterator, SceneIterator
+    rirs, scenes, noises = tmp_path / "rirs", tmp_path / "scenes", tmp_path / "noise"
+    for d in (rirs, scenes, noises):
+        d.mkdir()
+    rng = np.random.default_rng(0)
+    np.save(rirs / "src_b.npy", rng.standard_normal((2, 1000)).astype(np.float32))
+    np.save(rirs / "src_a.npy", rng.standard_normal((4, 70000)).astype(np.float32))
+    np.save(rirs / "n0_b.npy", rng.standard_normal((2, 64000)).astype(np.float32))
+    np.save(rirs / "n0_a.npy", rng.standard_normal((4, 10)).astype(np.float32))
+    region = {"region": {"scene": {"source": {"rir": {"binaural_rir_path": "/elsewhere/src_b.npy", "ambisonic_rir_path": "/x/src_a.npy"},
+                                              "azimuth": 30.0, "elevation": -5.0},
+                                   "noise": [{"rir": {"binaural_rir_path": "/y/n0_b.npy", "ambisonic_rir_path": "n0_a.npy"}}]}}}
+    (scenes / "s.json").write_text(json.dumps({"sampled_regions": [region]}))
+    it = iter(SceneIterator(str(rirs), str(scenes)))
+    src, nz, pos = next(it)
+    assert src.shape == (2, 64000) and src.dtype == torch.float32 and len(nz) == 1 and nz[0].shape == (2, 64000) and pos == [30.0, -5.0]
+    assert float(src[:, 1000:].abs().max()) == 0.0
+    src, nz, _ = next(SceneIterator(str(rirs), str(scenes), with_noise=False, ambisonic=True))
+    assert src.shape == (4, 64000) and nz == []
+    wavfile.write(noises / "a.wav", 16000, (rng.standard_normal(800) * 8000).astype(np.int16))
+    wavfile.write(noises / "b.wav", 8000, (rng.standard_normal((500, 2)) * 8000).astype(np.int16))
+    seen = set()
+    ni = iter(NoiseIterator(str(noises)))
+    for _ in range(40):
+        data, sr = next(ni)
+        assert data.dtype == torch.float32 and float(data.abs().max()) < 1.0
+        assert (tuple(data.shape), sr) in {((1, 800), 16000), ((2, 500), 8000)}
+        seen.add(sr)
+    assert seen == {16000, 8000}

@@ -174,3 +174,40 @@ def test_nat_workload_scene_front_end_feeds_two_channel_step():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["workload_name"] == "2s-nat" and line["config"]["seq_len"] == 400 and line["value"] > 0
     assert np.isfinite(line["final_loss"])
+
+
+def test_hear_api_scene_twin_matches_reference_fixture(golden_dir):
+    """hear_api/heaRIR (evaluation-time augmentation, reference hear_api/heaRIR/): every function of scene_module against the
+    reference's own outputs (hear_scene.npz) and Augmenter.augment against the oracle."""
+    from hear_api.heaRIR import Augmenter
+    from hear_api.heaRIR.scene_module import generate_scenes as H
+    fx = dict(np.load(os.path.join(golden_dir, "hear_scene.npz")))
+    sr = int(fx["sr"])
+    src, srir = cu(fx["source"]), cu(fx["source_rir"])
+    nr = [cu(fx["noise_rir0"]), cu(fx["noise_rir1"])]
+    assert err(H.convolve_with_rir(src, srir), fx["conv"]) < TOL
+    assert err(H.convolve_with_rir(src, srir[0]), fx["conv_1d_rir"]) < TOL
+    assert err(H.add_noise(cu(fx["mix_w"]), cu(fx["mix_n"]), cu(fx["mix_snr"])), fx["mix_full"]) < TOL
+    assert err(H.add_noise(cu(fx["mix_w"]), cu(fx["mix_n"]), cu(fx["mix_snr"]), cu(fx["mix_len"])), fx["mix_lengths"]) < TOL
+    assert err(H.fade_noise(cu(fx["noise_long"]), src, sr), fx["fade_long"]) < 1e-6
+    assert err(H.fade_noise(cu(fx["noise_short"]), src, sr), fx["fade_short"]) < 1e-6
+    assert err(H.generate_scene(srir, nr, src.clone(), cu(fx["noise_same"]), 7.0, sr), fx["scene_same"]) < TOL
+    assert err(H.generate_scene(srir, nr, src.clone(), cu(fx["noise_long"]), 0.0, sr), fx["scene_long"]) < TOL
+    np.random.seed(5)
+    assert err(H.generate_scene(srir, nr, src.clone(), cu(fx["noise_short"]), 12.0, sr), fx["scene_short"]) < TOL
+    assert err(H.generate_scene(srir, [], src.clone(), None, 5.0, sr), fx["scene_no_noise"]) < TOL
+
+    class OneScene:                                   # stands in for SceneIterator: one fixed scene, RIR longer than the clip
+        def __next__(self):
+            return torch.from_numpy(fx["source_rir"]), [torch.from_numpy(fx["noise_rir0"])], [0.0, 0.0]
+    fsr = 1000                                       # (sr only sets the 0.2 s fades: 200 samples here)
+    aug = Augmenter(OneScene(), sr=fsr, snr=9)
+    clip = cu(fx["source"][:500])                    # 500 samples < 800 taps: the clip is zero-extended, the result cut back
+    pad = np.concatenate([fx["source"][:500], np.zeros(300, np.float32)])
+    ref = S.hear_generate_scene(fx["source_rir"], [fx["noise_rir0"]], pad, fx["noise_same"][:500], 9.0, fsr,
+                                rng=np.random.RandomState(0))
+    np.random.seed(0)
+    out = aug.augment(clip.clone(), cu(fx["noise_same"][:500]))
+    assert out.shape == (2, 500)
+    assert err(out, ref[:, :500]) < TOL
+    assert Augmenter(None, sr=sr, snr=None).augment(clip).shape == (1, 500)
