@@ -1,0 +1,225 @@
+"""The real data path on the CPU: native FLAC decoder (round trips through an independent encoder that can force
+every bitstream feature, CRC / MD5 / truncation detection), the per-file preparation functions against the reference's own, the
+CPU resampler against the oracle, and the shard-based data module end to end on temporary tar shards."""
+import io
+import os
+import sys
+import tarfile
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import flac_encoder as E  # noqa: E402
+from wavjepa_amd import audio_io as A  # noqa: E402
+
+
+def tone_pcm(n, ch, bps, seed=0, rate=16000):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    amp = (1 << (bps - 1)) * 0.4
+    cols = []
+    for c in range(ch):
+        x = amp * np.sin(2 * np.pi * (220.0 * (c + 1)) * t / rate) + amp * 0.02 * rng.standard_normal(n)
+        cols.append(np.round(x).astype(np.int64))
+    if ch == 2:
+        cols[1] = (cols[0] * 0.8).astype(np.int64) + rng.integers(-20, 20, n)
+    return np.stack(cols, 1)
+
+
+SPECS = [dict(kind="verbatim"), dict(kind="fixed", order=0), dict(kind="fixed", order=1, porder=2), dict(kind="fixed", order=2, porder=3, rice2=True),
+         dict(kind="fixed", order=3, params=[3, 9, 0]), dict(kind="fixed", order=4, porder=4, escape_parts=(0, 1, 5)),
+         dict(kind="lpc", order=1, coefs=[1000], shift=10, precision=12), dict(kind="lpc", order=3, coefs=[1900, -1100, 150], shift=10, precision=12, porder=1),
+         dict(kind="lpc", order=8, coefs=[700, -300, 120, -60, 30, -20, 10, -5], shift=9, precision=11, porder=2, rice2=True),
+         dict(kind="lpc", order=32, coefs=[3] * 32, shift=7, precision=5, porder=0)]
+
+
+@pytest.mark.parametrize("stereo", ["independent", "left_side", "right_side", "mid_side"])
+def test_flac_round_trip_every_subframe_type_and_channel_assignment(stereo):
+    pcm = tone_pcm(9000, 2, 16)
+    for spec in SPECS:
+        data = E.encode(pcm, 16000, 16, blocksize=4096, stereo=stereo, subframes=spec)
+        out, si = A.decode_flac_pcm(data, verify_md5=True)
+        assert np.array_equal(out, pcm), (stereo, spec)
+        assert (si.sample_rate, si.channels, si.bits_per_sample, si.total_samples) == (16000, 2, 16, 9000)
+
+
+@pytest.mark.parametrize("bps", [8, 12, 16, 20, 24])
+@pytest.mark.parametrize("blocksize", [192, 200, 1000, 1152, 4096, 5000])
+def test_flac_bit_depths_and_block_sizes(bps, blocksize):
+    """Table block sizes, explicit 8-bit (200) and 16-bit (1000, 5000) sizes, a short last frame; mono and 3 channels."""
+    for ch in (1, 3):
+        pcm = tone_pcm(2 * blocksize + 77, ch, bps, seed=bps + blocksize)
+        data = E.encode(pcm, 44100, bps, blocksize=blocksize, subframes=dict(kind="fixed", order=2, porder=0))
+        out, si = A.decode_flac_pcm(data, verify_md5=True)
+        assert np.array_equal(out, pcm) and si.bits_per_sample == bps and si.channels == ch
+        wav, sr = A.decode_flac(data)
+        assert sr == 44100 and wav.shape == (ch, pcm.shape[0]) and wav.dtype == torch.float32
+        assert np.allclose(wav.numpy(), pcm.T / float(1 << (bps - 1)), atol=0)
+
+
+def test_flac_header_variants_and_special_subframes():
+    pcm = tone_pcm(6000, 2, 16, seed=5)
+    pcm[:, 1] = 1234                                                     # a constant channel
+    pcm[:, 0] &= ~0x7                                                    # three wasted bits
+    sub = [dict(kind="fixed", order=2, wasted=3), dict(kind="constant")]
+    blocks = [(4, b"\x00" * 40), (1, b"\x00" * 100)]                     # a VORBIS_COMMENT-sized block and PADDING after STREAMINFO
+    for kw in (dict(), dict(variable=True), dict(sr_in_header="streaminfo", bps_in_header=False), dict(id3=True, extra_blocks=blocks),
+               dict(total_in_header=False, md5=False)):
+        data = E.encode(pcm, 32000, 16, blocksize=1024, subframes=sub, **kw)
+        out, si = A.decode_flac_pcm(data, verify_md5=True)
+        assert np.array_equal(out, pcm), kw
+    for rate, mode in ((37000, "khz"), (12345, "hz"), (96010, "tens")):  # explicit sample-rate codes 12 / 13 / 14
+        data = E.encode(pcm, rate, 16, blocksize=1024, subframes=sub, sr_in_header=mode)
+        out, si = A.decode_flac_pcm(data)
+        assert np.array_equal(out, pcm) and si.sample_rate == rate
+
+
+def test_flac_detects_corruption():
+    pcm = tone_pcm(5000, 1, 16, seed=9)
+    data = bytearray(E.encode(pcm, 16000, 16, blocksize=1024))
+    good = bytes(data)
+    assert np.array_equal(A.decode_flac_pcm(good, verify_md5=True)[0], pcm)
+    start = good.index(b"\xff\xf8", 42)
+    bad = bytearray(good)
+    bad[start + 40] ^= 0x10                                              # a bit in the first frame's body: frame CRC-16
+    with pytest.raises(A.AudioDecodeError, match="CRC|malformed|truncated|unsupported"):
+        A.decode_flac_pcm(bytes(bad))
+    bad = bytearray(good)
+    bad[start + 2] ^= 0x10                                               # header byte: CRC-8
+    with pytest.raises(A.AudioDecodeError):
+        A.decode_flac_pcm(bytes(bad))
+    with pytest.raises(A.AudioDecodeError, match="truncated"):
+        A.decode_flac_pcm(good[: len(good) // 2])
+    bad = bytearray(good)
+    bad[8 + 18 + 3] ^= 0xff                                              # STREAMINFO MD5
+    A.decode_flac_pcm(bytes(bad))                                        # frames are fine ...
+    with pytest.raises(A.AudioDecodeError, match="MD5"):
+        A.decode_flac_pcm(bytes(bad), verify_md5=True)                   # ... the signature is not
+    with pytest.raises(A.AudioDecodeError):
+        A.decode_flac_pcm(b"RIFF" + bytes(100))
+    with pytest.raises(A.AudioDecodeError):
+        A.decode_audio(good, "mp3")
+
+
+def test_dataset_functions_match_the_reference():
+    """Against the reference's own data_modules/dataset_functions.py when it is present (this container); known answers otherwise."""
+    from wavjepa_amd.data_modules import dataset_functions as F
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(30000, generator=g) * 0.05
+    y = F.normalize_audio(x)
+    assert abs(20 * float(torch.log10(torch.sqrt(torch.mean(y ** 2)))) + 14.0) < 1e-4
+    assert torch.equal(F.normalize_audio(torch.zeros(10)), torch.zeros(10))
+    assert F.pre_process(x, 16000).shape == (1, 160000) and float(F.pre_process(x, 16000)[0, 30000:].abs().max()) == 0.0
+    assert F.pre_process(torch.randn(200000, generator=g), 16000).shape == (1, 160000)
+    assert F.pad_or_truncate(torch.ones(2, 5), 8).shape == (2, 8) and F.pad_or_truncate_batch(torch.ones(3, 2, 9), 4).shape == (3, 2, 4)
+    ref_path = "/root/reference/data_modules/dataset_functions.py"
+    if os.path.exists(ref_path):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_dataset_functions", ref_path)
+        R = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(R)
+        for n in (1000, 160000, 170001):
+            w = torch.randn(n, generator=g) * 0.3
+            assert torch.allclose(F.pre_process(w, 16000), R.pre_process(w, 16000), rtol=1e-6, atol=1e-7)
+            assert torch.allclose(F.pre_process_noise(w), R.pre_process_noise(w), rtol=1e-6, atol=1e-7)
+            assert torch.allclose(F.instance_normalize(w), R.instance_normalize(w), rtol=1e-6, atol=1e-7)
+        f2 = torch.randn(2, 50, generator=g)
+        for tl in (30, 50, 70):
+            assert torch.equal(F.pad_or_truncate(f2, tl), R.pad_or_truncate(f2, tl))
+            assert torch.equal(F.pad_or_truncate_batch(f2[None], tl), R.pad_or_truncate_batch(f2[None], tl))
+
+
+def test_cpu_resampler_vs_oracle():
+    from oracle import resample_oracle as RS
+    from wavjepa_amd.resample import KAISER_BEST, resample_waveform_cpu
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 5003)).astype(np.float32)
+    for orig, new in ((44100, 16000), (32000, 16000), (48000, 16000), (8000, 16000)):
+        y = resample_waveform_cpu(torch.from_numpy(x), orig, new, resampling_method="sinc_interp_kaiser", **KAISER_BEST)
+        ref = RS.resample(x, orig, new)
+        assert tuple(y.shape) == ref.shape and np.abs(y.numpy() - ref).max() < 2e-5 * np.sqrt((ref ** 2).mean())
+    assert resample_waveform_cpu(torch.from_numpy(x), 16000, 16000) is not None
+
+
+def make_shard(path, clips):
+    """clips: list of (key, member bytes by extension)"""
+    with tarfile.open(path, "w") as tf:
+        for key, members in clips:
+            for ext, data in members.items():
+                ti = tarfile.TarInfo(f"{key}.{ext}")
+                ti.size = len(data)
+                tf.addfile(ti, io.BytesIO(data))
+
+
+def test_web_audio_data_module_end_to_end(tmp_path):
+    from wavjepa_amd.data_modules import WebAudioDataModule
+    from wavjepa_amd.data_modules.WebAudioDataModule import iterate_shard
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    rng = np.random.default_rng(0)
+    clips_a, clips_b = [], []
+    for i in range(6):
+        rate = [16000, 32000, 44100][i % 3]
+        pcm = tone_pcm(int(rate * (0.6 + 0.2 * i)), 1 + (i % 2), 16, seed=i, rate=rate)
+        flac = E.encode(pcm, rate, 16, blocksize=4096, stereo="mid_side" if pcm.shape[1] == 2 else "independent",
+                        subframes=dict(kind="fixed", order=2, porder=2))
+        clips_a.append((f"audio/clip{i:03d}", {"flac": flac, "json": b"{}"}))
+    clips_a.append(("audio/broken", {"flac": clips_a[0][1]["flac"][:300]}))                 # undecodable member: skipped with a warning
+    clips_a.append(("audio/noflac", {"txt": b"no audio here"}))
+    silent = E.encode(np.zeros((8000, 1), np.int64), 16000, 16, subframes=dict(kind="constant"))
+    clips_b.append(("b/silence", {"flac": silent}))
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    make_shard(tmp_path / "a" / "shard-000.tar", clips_a[:4])
+    make_shard(tmp_path / "a" / "shard-001.tar", clips_a[4:])
+    make_shard(tmp_path / "b" / "shard-000.tar", clips_b)
+    keys = [s["__key__"] for s in iterate_shard(str(tmp_path / "a" / "shard-000.tar"))]
+    assert keys == [f"audio/clip{i:03d}" for i in range(4)]
+    masker = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)
+
+    class DM(WebAudioDataModule):
+        SHUFFLE, NUM_WORKERS, PREFETCH_FACTOR = 4, 2, 1
+
+    dm = DM(masker, str(tmp_path / "a" / "shard-{000..001}.tar"), None, batch_size=3, nr_samples_per_audio=2, nr_time_points=200, sr=16000, seed=7)
+    dm.setup("fit")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        it = iter(dm.train_dataloader())
+        batches = [next(it) for _ in range(4)]
+        del it
+    assert DM.NUM_WORKERS == 2          # (worker processes: their warnings surface on stderr, not in this process)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        g0 = dm._batches(0, 1)
+        for _ in range(4):
+            next(g0)
+    assert any("broken" in str(w.message) for w in caught)
+    for audio, ctx, tgt, vis in batches:
+        assert audio.shape == (3, 1, 160000) and audio.dtype == torch.float32 and bool(torch.isfinite(audio).all())
+        assert ctx.shape == (3, 2, 200) and tgt.shape == (3, 2, 4, 200) and vis.shape == (3, 2, 4, 200) and ctx.dtype == torch.bool
+        for clip in audio[:, 0]:
+            n = int((clip != 0).nonzero().max()) + 1                     # the file's own samples (before the zero padding)
+            rms_db = 20 * float(torch.log10(torch.sqrt(torch.mean(clip ** 2) * 160000 / 160000)))
+            full = 20 * float(torch.log10(torch.sqrt(torch.sum(clip ** 2) / n)))
+            assert n < 160000 and abs(full + 14.0) < 0.05, (n, rms_db, full)          # -14 dBFS over the un-padded part
+    # same seed / rank -> same stream; another rank -> a different one
+    def first(rank):
+        d = DM(masker, str(tmp_path / "a"), None, batch_size=2, nr_samples_per_audio=2, nr_time_points=200, seed=3, rank=rank, world_size=2)
+        d.NUM_WORKERS = 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g = d._batches(0, 1)
+            return [next(g)[0] for _ in range(3)]
+    a0, a0b, a1 = first(0), first(0), first(1)
+    assert all(torch.equal(x, y) for x, y in zip(a0, a0b))
+    assert not all(torch.equal(x, y) for x, y in zip(a0, a1))
+    # mixing: weight 0 for the speech-like shards -> only the silent source is drawn
+    mix = DM(masker, [str(tmp_path / "a"), str(tmp_path / "b")], [0.0, 1.0], batch_size=2, nr_samples_per_audio=2, nr_time_points=200, seed=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        audio = next(mix._batches(0, 1))[0]
+    assert float(audio.abs().max()) == 0.0
+    with pytest.raises(FileNotFoundError):
+        DM(masker, str(tmp_path / "nothing-*.tar"), None).setup("fit")

@@ -211,3 +211,32 @@ def test_hear_api_scene_twin_matches_reference_fixture(golden_dir):
     assert out.shape == (2, 500)
     assert err(out, ref[:, :500]) < TOL
     assert Augmenter(None, sr=sr, snr=None).augment(clip).shape == (1, 500)
+
+
+def test_train_py_runs_on_flac_shards(tmp_path):
+    """The real data path end to end: tar shards of FLAC clips -> WebAudioDataModule worker processes (native decoder,
+    resampling, -14 dBFS, 10 s pad, masks) -> train.py's loop on the GPU for three optimisation steps."""
+    import io
+    import subprocess
+    import sys
+    import tarfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import flac_encoder as E
+    rng = np.random.default_rng(0)
+    shard = tmp_path / "shard-000.tar"
+    with tarfile.open(shard, "w") as tf:
+        for i in range(6):
+            rate = (16000, 32000)[i % 2]
+            n = int(rate * 2.6)
+            pcm = np.round(6000 * np.sin(2 * np.pi * (200 + 40 * i) * np.arange(n) / rate) + 500 * rng.standard_normal(n)).astype(np.int64)[:, None]
+            data = E.encode(pcm, rate, 16, blocksize=4096, subframes=dict(kind="fixed", order=2, porder=2))
+            ti = tarfile.TarInfo(f"clip{i:03d}.flac")
+            ti.size = len(data)
+            tf.addfile(ti, io.BytesIO(data))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train.py"), "data=audioset", f"data.data_dirs={shard}", "trainer.batch_size=2", "trainer.steps=3",
+           "trainer.log_every_n_steps=1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    losses = [float(ln.split("loss")[1].split()[0]) for ln in r.stdout.splitlines() if ln.startswith("step ")]
+    assert len(losses) >= 3 and all(np.isfinite(losses)), r.stdout[-1500:]

@@ -87,9 +87,14 @@ def build_model(cfg):
 
 def create_data_source(cfg, nr_patches, device, rank):
     masker = ComponentFactory.create_masker(cfg)
-    if cfg.data.name != "Synthetic":
-        raise NotImplementedError("the webdataset loader (reference data_modules/WebAudioDataModule.py) is a 'next' row "
-                                  "(SURVEY §8 f3); use data=synthetic")
+    if cfg.data.name != "Synthetic":        # tar shards of .flac clips (reference train.py:94-110 -> data_modules/WebAudioDataModule.py)
+        from wavjepa_amd.data_modules import WebAudioDataModule
+        dm = WebAudioDataModule(masker, data_dirs=cfg.data.data_dirs, mixing_weights=cfg.data.get("mixing_weights", None),
+                                batch_size=cfg.trainer.batch_size, nr_samples_per_audio=cfg.data.samples_per_audio,
+                                nr_time_points=nr_patches, in_channels=cfg.data.in_channels, sr=cfg.data.sr, seed=cfg.seed, rank=rank,
+                                world_size=cfg.trainer.num_gpus)
+        dm.setup("fit")
+        return dm.train_dataloader()
     return SyntheticAudioSource(masker, batch_size=cfg.trainer.batch_size, samples_per_audio=cfg.data.samples_per_audio,
                                 n_tokens=nr_patches, in_channels=cfg.data.in_channels, sr=cfg.data.sr,
                                 seconds=cfg.data.get("source_seconds", 10.0), seed=cfg.seed + rank, device=device)

@@ -63,7 +63,28 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"link failed:\n{r.stderr}")
         if verbose:
             print(f"[wavjepa_amd.build] linked {LIB}", file=sys.stderr)
+    build_io(force=force, verbose=verbose)
     return LIB
+
+
+IO_LIB = os.path.join(LIBDIR, "libwavjepa_io.so")
+IO_SOURCES = ["flac_decode.cpp"]
+
+
+def build_io(force: bool = False, verbose: bool = True) -> str:
+    """Host-side library of the data path (FLAC decoder): plain C++ with a C ABI, built with g++ (no GPU code)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in IO_SOURCES]
+    if force or _stale(IO_LIB, srcs):
+        cxx = shutil.which("g++") or shutil.which("c++")
+        if cxx is None:
+            raise RuntimeError("g++ not found: needed for libwavjepa_io.so")
+        r = subprocess.run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", IO_LIB] + srcs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed for libwavjepa_io.so:\n{r.stderr}")
+        if verbose:
+            print(f"[wavjepa_amd.build] built {IO_LIB}", file=sys.stderr)
+    return IO_LIB
 
 
 if __name__ == "__main__":

@@ -72,3 +72,28 @@ def resample_waveform(waveform: torch.Tensor, orig_freq: int, new_freq: int, low
 def resample(audio: torch.Tensor, resample_sr: int, original_sr: int = 32000) -> torch.Tensor:
     """reference wavjepa/denoiser.py:29-42 ("kaiser best")."""
     return resample_waveform(audio, original_sr, resample_sr, resampling_method="sinc_interp_kaiser", **KAISER_BEST)
+
+
+def resample_waveform_cpu(waveform: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99,
+                          resampling_method: str = "sinc_interp_hann", beta=None) -> torch.Tensor:
+    """The same algorithm on a CPU tensor, for the loader workers (one clip at a time, any rate pair; the reference resamples there
+    too: WebAudioDataModule.py:50-60).  Strided windows x table, float32."""
+    if orig_freq == new_freq:
+        return waveform
+    kern, width, orig, new = sinc_resample_kernel(int(orig_freq), int(new_freq), int(lowpass_filter_width), float(rolloff),
+                                                  resampling_method, beta)
+    shape = waveform.shape
+    x = waveform.reshape(-1, shape[-1]).to(torch.float32).numpy()
+    L = shape[-1]
+    pad = np.pad(x, ((0, 0), (width, width + orig)))
+    if new * orig <= 8:
+        # few phases and a short stride (32 -> 16 kHz: one phase, stride 2): overlap-add FFT correlation of the whole clip per phase,
+        # then the stride -- 7x faster than gathering 274-tap windows for a matrix product
+        from scipy.signal import oaconvolve
+        out = np.stack([oaconvolve(pad, kern[p][None, ::-1], mode="valid", axes=1)[:, ::orig] for p in range(new)], axis=-1)
+        out = out.reshape(x.shape[0], -1).astype(np.float32)
+    else:
+        win = np.lib.stride_tricks.sliding_window_view(pad, kern.shape[1], axis=1)[:, ::orig]  # [B, frames, taps] (a view)
+        out = np.matmul(win, kern.T).reshape(x.shape[0], -1)
+    target = int(math.ceil(new * L / orig))
+    return torch.from_numpy(np.ascontiguousarray(out[:, :target])).view(shape[:-1] + (target,))
