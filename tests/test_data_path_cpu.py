@@ -223,3 +223,54 @@ def test_web_audio_data_module_end_to_end(tmp_path):
     assert float(audio.abs().max()) == 0.0
     with pytest.raises(FileNotFoundError):
         DM(masker, str(tmp_path / "nothing-*.tar"), None).setup("fit")
+
+
+def test_denoiser_data_module_batches(tmp_path):
+    """WebAudioDataModuleDenoiser (reference data_modules/WebAudioDataModuleDenoiser.py): the 7-field batch the Denoiser hook consumes,
+    from FLAC clip shards + .npy RIR-set shards + .npy noise shards, with and without RIRs / noise."""
+    from wavjepa_amd.data_modules import WebAudioDataModuleDenoiser
+    from wavjepa_amd.data_modules.WebAudioDataModuleDenoiser import fade_noise
+    rng = np.random.default_rng(3)
+    clips = []
+    for i in range(5):
+        rate = (32000, 16000)[i % 2]
+        pcm = tone_pcm(int(rate * 0.5), 1, 16, seed=20 + i, rate=rate)
+        clips.append((f"c{i}", {"flac": E.encode(pcm, rate, 16, subframes=dict(kind="fixed", order=1))}))
+    make_shard(tmp_path / "audio-000.tar", clips)
+
+    def npy(a):
+        b = io.BytesIO()
+        np.save(b, a)
+        return b.getvalue()
+    make_shard(tmp_path / "rir-000.tar", [(f"r{i}", {"npy": npy(rng.standard_normal((3, 2, 400)).astype(np.float32))}) for i in range(4)])
+    make_shard(tmp_path / "noise-000.tar", [("short", {"npy": npy(rng.standard_normal(50000).astype(np.float32))}),
+                                             ("long", {"npy": npy(rng.standard_normal(400000).astype(np.float32))})])
+
+    class DM(WebAudioDataModuleDenoiser):
+        NUM_WORKERS, SHUFFLE = 0, 4
+
+    dm = DM(str(tmp_path / "audio-000.tar"), str(tmp_path / "rir-000.tar"), str(tmp_path / "noise-000.tar"), batch_size=3, with_noise=True,
+            with_rir=True, nr_samples_per_audio=2, nr_time_points=200, seed=5)
+    it = iter(dm.train_dataloader())
+    seen_short = False
+    for _ in range(4):
+        audio, source_rir, noise, noise_length, noise_start, noise_rirs, snr = next(it)
+        assert audio.shape == (3, 320000) and source_rir.shape == (3, 2, 400) and noise.shape == (3, 320000) and noise_rirs.shape == (3, 2, 2, 400)
+        assert noise_length.shape == noise_start.shape == snr.shape == (3,)
+        assert bool(((snr >= -5) & (snr <= 5)).all())
+        for b in range(3):
+            n, st = int(noise_length[b]), int(noise_start[b])
+            assert n in (50000, 320000) and 0 <= st <= 320000 - n
+            assert float(noise[b, :st].abs().max() if st else 0.0) == 0.0 and float(noise[b, st + n:].abs().max() if st + n < 320000 else 0.0) == 0.0
+            seen_short |= n == 50000
+            assert abs(float(noise[b, st + n - 1])) < 1e-3                  # faded out
+    assert seen_short
+    plain = DM(str(tmp_path / "audio-000.tar"), "", "", batch_size=2, with_noise=False, with_rir=False, seed=1)
+    audio, source_rir, noise, noise_length, noise_start, noise_rirs, snr = next(iter(plain.train_dataloader()))
+    assert audio.shape == (2, 320000) and source_rir == [None, None] and noise == [None, None] and noise_rirs == [None, None] and snr == [None, None]
+    a = torch.zeros(1000)
+    torch.manual_seed(0)
+    f = fade_noise(torch.ones(5000), a, 1000)
+    assert f.shape == (1000,) and float(f[0]) == 1.0 and float(f[-1]) == 0.0
+    f = fade_noise(torch.ones(600), a, 1000)
+    assert f.shape == (600,) and float(f[0]) == 0.0 and float(f[-1]) == 0.0 and float(f[300]) == 1.0

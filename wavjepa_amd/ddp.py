@@ -67,9 +67,15 @@ class FlatGradAllReducer:
         self.module._ensure_engine()
         flat = self.module._flat
         dist.broadcast(flat.p32, 0, group=self.pg)
-        dist.broadcast(flat.t32, 0, group=self.pg)
+        if flat.tn > 0:
+            dist.broadcast(flat.t32, 0, group=self.pg)
         self.module._student_bf16_fresh = False
         self.module._teacher_bf16_fresh = False
+
+    def reduce_all(self) -> None:
+        """One average over the whole flat gradient buffer (modules whose backward exposes no section hooks: the denoiser stage)."""
+        if self.active:
+            self.handles.append(dist.all_reduce(self.module._flat.g32, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
 
     def hook(self, tag: str) -> None:
         if not self.active:

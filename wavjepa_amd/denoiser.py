@@ -230,9 +230,11 @@ class Denoiser(_ModuleBase):
         """reference denoiser.py:217-309: scene generation (source RIR + noise RIRs + SNR mix, receiver channel 0), 32 kHz -> `sr`
         kaiser-sinc resampling of the scene and of the clean source, the SAME random crops of both, per-crop normalisation, bf16,
         flatten, one shared shuffle.  Returns (generated, clean), each bf16 [B * S, 1, target_length]."""
-        audio, source_rir, noise, noise_length, noise_start_idx, noise_rirs, snr = batch
         self._ensure_engine()
         dev = self.device
+        # (Lightning calls this hook with the batch already on the device; the plain trainer hands over the loader's CPU batch)
+        audio, source_rir, noise, noise_length, noise_start_idx, noise_rirs, snr = (
+            t.to(dev, non_blocking=True) if isinstance(t, torch.Tensor) else t for t in batch)
         audio = audio.to(dev, dtype=torch.float32)
         generated = scene.generate_scene(source_rir=source_rir, source=audio, noise=noise, real_noise_length=noise_length,
                                          noise_start_idx=noise_start_idx, noise_rirs=noise_rirs, snr=snr)

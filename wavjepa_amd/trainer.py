@@ -38,7 +38,9 @@ class StepRunner:
         model._ensure_engine()
         self.reducer = FlatGradAllReducer(model, enc_chunk=enc_chunk)
         self.reducer.broadcast_parameters()
-        model._grads_ready_hook = self.reducer.hook if self.reducer.active else None
+        self.sectioned = hasattr(model, "_grads_ready_hook")      # JEPA: bucketed all-reduces launched from the backward's hooks
+        if self.sectioned:
+            model._grads_ready_hook = self.reducer.hook if self.reducer.active else None
         oc = model.configure_optimizers()
         self.optimizer = oc["optimizer"]
         self.scheduler = oc["lr_scheduler"]["scheduler"]
@@ -49,6 +51,8 @@ class StepRunner:
         batch = m.on_after_batch_transfer(raw_batch, 0)     # crops + normalise + bf16 on the device
         out = m.training_step(batch, batch_idx)             # forward + EMA of the teacher
         out["loss"].backward()                              # engine backward; buckets all-reduce as they complete
+        if not self.sectioned:
+            self.reducer.reduce_all()
         self.reducer.wait()
         self.optimizer.step()                               # fused global-norm clip + AdamW over the flat buffers
         self.scheduler.step()
@@ -111,7 +115,8 @@ class Trainer:
             if self.log_every_n_steps and gs % self.log_every_n_steps == 0 and self.rank == 0:
                 loss = float(out["loss"])          # the only host sync, every n steps
                 dt = time.time() - t0
-                print(f"step {gs}  loss {loss:.5f}  lr {runner.scheduler.get_last_lr()[0]:.3e}  ema {model._get_ema_decay():.6f}  "
+                ema = f"  ema {model._get_ema_decay():.6f}" if hasattr(model, "_get_ema_decay") else ""
+                print(f"step {gs}  loss {loss:.5f}  lr {runner.scheduler.get_last_lr()[0]:.3e}{ema}  "
                       f"{dt / self.log_every_n_steps * 1000:.1f} ms/step", flush=True)
                 t0 = time.time()
             if self.root and self.ckpt_every and gs % self.ckpt_every == 0:
