@@ -304,7 +304,8 @@ def ref_attention(qkv, H, mask):
 
 
 @pytest.mark.parametrize("B,T,H,hd", [(3, 200, 12, 64), (4, 200, 12, 32), (2, 49, 4, 64), (2, 24, 2, 32), (1, 224, 2, 64),
-                                      (2, 400, 12, 64), (2, 400, 12, 32), (1, 416, 2, 64), (2, 225, 2, 32)])
+                                      (2, 400, 12, 64), (2, 400, 12, 32), (1, 416, 2, 64), (2, 225, 2, 32),
+                                      (2, 129, 4, 32), (2, 150, 4, 32), (2, 192, 2, 32), (2, 193, 2, 32), (2, 150, 2, 64)])
 def test_attention_fwd_bwd(ops, B, T, H, hd):
     D = H * hd
     qkv = rnd(B, T, 3 * D, dtype=torch.bfloat16, seed=30)

@@ -68,6 +68,9 @@ def attention(tag, lens, H, hd, T_dense=None):
 attention("teacher", np.full(256, 200), 12, 64, T_dense=200)
 attention("student ragged", enc_len, 12, 64)
 attention("predictor ragged", dec_len, 12, 32)
+long_dec = dec_len.copy()
+long_dec[0] = 150                  # one sequence beyond 128 tokens moves the whole launch to the 129..192-token variants
+attention("predictor, Tmax 150", long_dec, 12, 32)
 
 for tag, M, D in (("teacher", 51200, 768), ("student ragged", int(enc_len.sum()), 768), ("predictor ragged", int(dec_len.sum()), 384)):
     x = torch.randn(M, D, device=dev)

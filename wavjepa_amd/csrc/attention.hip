@@ -127,7 +127,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // ------------------------------------------------------------------------------------------------ forward
 // MT = most 16-row tiles a sequence may have (14: T <= 224; 8: T <= 128, fewer live registers -> more waves per SIMD)
 template <int HD, int NWF, int MT>
-__global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 : 6) : 2)) void attn_fwd_kernel(wj_attn_fwd_args a) {
+__global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 : 6) : (MT == 12 ? 4 : 2))) void attn_fwd_kernel(wj_attn_fwd_args a) {
     constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, D = H * HD;
@@ -742,7 +742,10 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
         if (shortseq) hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_SHORT, 8>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_LONG, 14>), grid, dim3(NWF_LONG * 64), lds, st, *a);
     } else {
+        // 129 .. 192 tokens at head dim 32: the predictor's longest ragged sequences of a step now and then (one step in eight at the
+        // AudioSet mask parameters) -- three tiles per wave in the short-sequence kernel instead of the general one (105 -> ~75 us)
         if (shortseq) hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_SHORT, 8>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
+        else if (a->T <= 192) hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_SHORT, 12>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_LONG, 14>), grid, dim3(NWF_LONG * 64), lds, st, *a);
     }
     WJ_CHECK_LAUNCH();
@@ -782,6 +785,9 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
         }
     } else if (a->hd == 64) {
         hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 14>), grid, dim3(NWB64 * 64), lds, st, *a);
+    } else if (a->T <= 192) {          // 129 .. 192 tokens, head dim 32: the single-round-trip kernel with three tiles per wave
+        if (a->key_mask) hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 12, true>), grid, dim3(NWB32 * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 12, false>), grid, dim3(NWB32 * 64), lds, st, *a);
     } else {
         hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 14>), grid, dim3(NWB32 * 64), lds, st, *a);
     }
