@@ -113,7 +113,7 @@ class Trainer:
             out = runner.step(batch, model.global_step)
             gs = model.global_step
             if self.log_every_n_steps and gs % self.log_every_n_steps == 0 and self.rank == 0:
-                loss = float(out["loss"])          # the only host sync, every n steps
+                loss = float(out["loss"].detach())   # the only host sync, every n steps
                 dt = time.time() - t0
                 ema = f"  ema {model._get_ema_decay():.6f}" if hasattr(model, "_get_ema_decay") else ""
                 print(f"step {gs}  loss {loss:.5f}  lr {runner.scheduler.get_last_lr()[0]:.3e}{ema}  "
