@@ -125,6 +125,34 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
         assert e < 3e-2, (g, e)
 
 
+def test_stock_pytorch_autocast_yardstick_base_model(golden_dir):
+    """SURVEY 3.2 / north star ("encoder outputs within 1e-3 rel in bf16"): what does PyTorch's OWN bf16 autocast on this GPU do to the
+    same model?  The oracle's fp32 code path is run under `torch.autocast("cuda", dtype=torch.bfloat16)` -- PyTorch's cast policy on
+    the box decides every dtype (conv / linear / matmul in bf16, norms / softmax / loss in fp32), not the oracle's emulation of it --
+    next to the plain fp32 run (the truth) and the HIP path, base model, same weights and clips.  The HIP path must sit as close to
+    the fp32 truth as stock autocast does (x1.25), and within that same distance of stock autocast itself; the loss within 1e-3."""
+    m, P = build(BASE)
+    ctx, tgt, vis = masks(golden_dir, 2)
+    audio = torch.from_numpy(synth.synth_audio(2, 1, 32159, seed=3)).to(torch.bfloat16).to(dev())
+    with torch.no_grad():
+        out = m(audio, ctx, tgt, vis)
+        args = (audio.float(), ctx.to(dev()), tgt.to(dev()), vis.to(dev()))
+        Pd = {k: v.detach() for k, v in P.items()}
+        ref32 = J.jepa_forward(Pd, *args, mode="fp32", **oracle_kw(BASE))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            stock = J.jepa_forward(Pd, *args, mode="fp32", **oracle_kw(BASE))
+    rep = {}
+    for k in ("local_features", "contextual_features", "targets"):
+        rep[k] = dict(hip_vs_fp32=rel(out[k].float(), ref32[k].float()), stock_autocast_vs_fp32=rel(stock[k].float(), ref32[k].float()),
+                      hip_vs_stock_autocast=rel(out[k].float(), stock[k].float()))
+    lh, ls, l32 = float(out["loss"]), float(stock["loss"]), float(ref32["loss"])
+    print("stock-autocast yardstick (rel L2):", rep, "loss hip / stock autocast / fp32:", lh, ls, l32)
+    for k, r in rep.items():
+        assert r["hip_vs_fp32"] < 1.25 * r["stock_autocast_vs_fp32"] + 1e-4, (k, r)
+        assert r["hip_vs_stock_autocast"] < 1.5 * r["stock_autocast_vs_fp32"] + 1e-4, (k, r)
+    assert abs(lh - ls) < 1e-3 * abs(ls), (lh, ls)
+
+
 def test_forward_backward_parity_speech_masks(golden_dir):
     """The LibriSpeech masker's masks (short, clustered targets; long contexts) through the ragged path."""
     m, P = build(SMALL)
