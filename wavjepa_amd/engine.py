@@ -28,6 +28,8 @@ def _empty(*shape, dtype, device):
     them instead, so that a read of never-written memory shows up as NaN in the results (tools/debug_order.py)."""
     import os
     if os.environ.get("WJ_ARENA_FILL", "") == "nan":
+        if not dtype.is_floating_point:          # fp8 operand bytes: 0x7f is the e4m3 NaN encoding
+            return torch.full(shape, 0x7f, dtype=dtype, device=device)
         return torch.full(shape, float("nan"), dtype=dtype, device=device)
     return torch.empty(*shape, dtype=dtype, device=device)
 
