@@ -141,3 +141,55 @@ def test_ddp_gradient_equals_mean_of_per_rank_gradients_world2():
     for rank, worst, counts in res:
         assert counts[0] != counts[1], "the two micro-batches should have different target counts"
         assert worst < 1e-5, f"rank {rank}: averaged gradient deviates by {worst}"
+
+
+def _denoiser_worker(rank, world, port, q):
+    """Denoiser stage under data parallelism: a module without an EMA copy (empty teacher buffer) broadcasts its parameters and averages
+    its whole flat gradient buffer in one collective (`FlatGradAllReducer.reduce_all`; the stage has no backward section hooks)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from wavjepa_amd.ddp import FlatGradAllReducer
+        from wavjepa_amd.denoiser import Denoiser
+        from wavjepa_amd.extractors import ConvFeatureExtractor
+        from wavjepa_amd.params import FlatParams
+        from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+        torch.manual_seed(200 + rank)
+        m = Denoiser(ConvFeatureExtractor(conv_layers_spec=[(32, 10, 5)] + [(32, 3, 2)] * 4 + [(32, 2, 2)], in_channels=1),
+                     TransformerLayerCFG.create(d_model=64, nhead=2), TransformerEncoderCFG.create(num_layers=2))
+        m._flat = FlatParams(m, torch.device("cpu"))
+        assert m._flat.tn == 0 and m._flat.owns(m)
+        m._ensure_engine = lambda: None
+        red = FlatGradAllReducer(m)
+        red.broadcast_parameters()
+        flat = m._flat
+        ref = flat.p32.clone()
+        dist.broadcast(ref, 0)
+        same = bool(torch.equal(ref, flat.p32))
+        flat.g32.copy_(torch.randn(flat.n, generator=torch.Generator().manual_seed(9 + rank)))
+        mine = flat.g32.clone()
+        red.reduce_all()
+        red.wait()
+        other = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        q.put((rank, same, float((flat.g32 - sum(other) / world).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_denoiser_stage_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_denoiser_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, same, err in res:
+        assert same and err < 1e-6, (rank, same, err)
