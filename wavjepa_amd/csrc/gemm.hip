@@ -235,14 +235,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   * a K tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each (16 MFMAs); every phase =
 //     [fragment reads + LDS-DMA issue] -> barrier -> [MFMA cluster] -> barrier.  Waves 4-7 run one barrier behind waves 0-3,
 //     so on every SIMD one wave's MFMA cluster overlaps its partner's reads / DMA issue.
-//   * staging is by half tiles (128 rows x 64 k = 16 KiB = 2 LDS-DMA instructions per wave): A halves of tile t+1 are issued
-//     in phases 0 / 1 of tile t, both B halves of tile t+2 in phase 3 of tile t (B fragments are read in phases 0 / 1 only and the
-//     first ones stay in registers for phase 3), so a slot is re-staged >= 2 phases after its last read; ONE counted
-//     s_waitcnt vmcnt(4) per K tile (phase 3) retires tile t+1 and leaves tile t+2's B halves in flight; tile t+1 is first read
-//     one phase after that wait (the staggered group's wait sits one barrier later, still before that read).
+//   * B fragments are read in phases 0 / 1 only (the first ones stay in registers for phase 3), A fragments in phases 0 / 2; a slot
+//     is re-staged >= 2 phases after its last read, and data is first read one phase after the counted wait that retires it (the
+//     staggered group's wait sits one barrier later, still before that read).
+// Staging by USAGE PHASE ("one 16-KiB piece per phase").  The first version of this loop staged 128-row HALF tiles: the A rows of tile
+// t+1 went out in phases 0 / 1 of tile t and were waited for in phase 3 -- two to three phases (~1 k cycles) of flight, less than an L2
+// miss takes -- because a half tile of A is read in phases 0 AND 2 and may only be restaged two phases after its last read (8192^3:
+// 1045 TFLOP/s; the loop stalled on that wait).  Now an operand tile is cut by the phase that READS it (8192^3: 1359 TFLOP/s, the
+// teacher's in_proj 852 -> 937, linear2 1026 -> 1082; outputs bit-identical):
+//     X  = A rows 0-63   of each wave row  (read in phase 0)        Y  = A rows 64-127 (phase 2)
+//     B0 = B rows 0-31   of each wave col  (phase 0, kept for 3)    B1 = B rows 32-63  (phase 1)
+// each 128 rows x 128 B = 16 KiB = 2 LDS-DMA instructions per wave, so a piece's slot is free two phases after ITS read and every
+// phase stages exactly one piece:   P0: Y(t+1)   P1: B1(t+1)   P2: B0(t+2)   P3: X(t+2)      (flight: 6 / 4 / 6 / 5 phases)
+// Two counted waits per tile: phase 3 retires X(t+1), B0(t+1) (vmcnt(8): Y(t+1), B1(t+1), B0(t+2), X(t+2) stay in flight), phase 0
+// retires B1(t) and with it the older Y(t) (vmcnt(6)); each is followed by a barrier before the phase that reads the data.
 template <int PAR>
-__device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const char* (&pa)[4], const char* (&pb)[4], unsigned a_lo,
-                                        unsigned b_lo, int wave, bool more1, bool more2) {
+__device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const char* (&px)[2], const char* (&py)[2], const char* (&pb0)[2],
+                                         const char* (&pb1)[2], const unsigned (&dx)[2], const unsigned (&db)[2], unsigned a_lo, unsigned b_lo,
+                                         bool more1, bool more2) {
     constexpr unsigned BUF = 65536u, BOFF = 32768u;
     char* cur = smem + PAR * BUF;
     char* oth = smem + (PAR ^ 1) * BUF;
@@ -253,13 +263,18 @@ __device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const ch
         __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst, 16, 0, 0);
         src += 128;
     };
-    // ---- phase 0: A rows 0-63 (of the wave's 128), B cols 0-31 (of its 64)
+    // ---- phase 0: X, B0 of this tile; stage Y(t+1); wait for B1(t)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 0; x < 2; ++x) { b0f[2 * x] = lds(b_lo + x * 2048); b0f[2 * x + 1] = lds(b_hi + x * 2048); }
 #pragma unroll
     for (int x = 0; x < 4; ++x) { af[2 * x] = lds(a_lo + x * 2048); af[2 * x + 1] = lds(a_hi + x * 2048); }
-    if (more1) { dma(pa[0], oth + (wave * 2) * 1024); dma(pa[1], oth + (wave * 2 + 1) * 1024); }
+    if (more1) {
+        dma(py[0], oth + dx[0] + 8192); dma(py[1], oth + dx[1] + 8192);
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -273,11 +288,11 @@ __device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const ch
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 1: B cols 32-63
+    // ---- phase 1: B1 of this tile; stage B1(t+1)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 0; x < 2; ++x) { b1f[2 * x] = lds(b_lo + 4096 + x * 2048); b1f[2 * x + 1] = lds(b_hi + 4096 + x * 2048); }
-    if (more1) { dma(pa[2], oth + 16384 + (wave * 2) * 1024); dma(pa[3], oth + 16384 + (wave * 2 + 1) * 1024); }
+    if (more1) { dma(pb1[0], oth + BOFF + db[0] + 4096); dma(pb1[1], oth + BOFF + db[1] + 4096); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -291,10 +306,11 @@ __device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const ch
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 2: A rows 64-127
+    // ---- phase 2: Y of this tile; stage B0(t+2) into THIS parity (its B0 rows were read two phases ago)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 0; x < 4; ++x) { af[2 * x] = lds(a_lo + 8192 + x * 2048); af[2 * x + 1] = lds(a_hi + 8192 + x * 2048); }
+    if (more2) { dma(pb0[0], cur + BOFF + db[0]); dma(pb0[1], cur + BOFF + db[1]); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -308,11 +324,12 @@ __device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const ch
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 3: no fragment reads; B of tile t+2 into THIS parity (its B rows were last read two phases ago); the wait
+    // ---- phase 3: no fragment reads; stage X(t+2) into THIS parity (read in phase 0); wait for X(t+1), B0(t+1)
     __builtin_amdgcn_sched_barrier(0);
     if (more2) {
-        dma(pb[0], cur + BOFF + (wave * 2) * 1024); dma(pb[1], cur + BOFF + (wave * 2 + 1) * 1024);
-        dma(pb[2], cur + BOFF + 16384 + (wave * 2) * 1024); dma(pb[3], cur + BOFF + 16384 + (wave * 2 + 1) * 1024);
+        dma(px[0], cur + dx[0]); dma(px[1], cur + dx[1]);
+        wait_vmcnt<8>();
+    } else if (more1) {
         wait_vmcnt<4>();
     } else {
         wait_vmcnt<0>();
@@ -333,36 +350,49 @@ __device__ __forceinline__ void ep_tile(f32x4 (&acc)[8][4], char* smem, const ch
 }
 
 __device__ __forceinline__ void eight_phase_loop(f32x4 (&acc)[8][4], char* smem, const bf16_t* __restrict__ A,
-                                                 const bf16_t* __restrict__ B, long lda, long ldb, int m0, int n0, int M, int N, int K,
-                                                 int wave, int lane) {
+                                                  const bf16_t* __restrict__ B, long lda, long ldb, int m0, int n0, int M, int N, int K,
+                                                  int wave, int lane) {
     constexpr unsigned BUF = 65536u, BOFF = 32768u;
     const int nkt = K / 64;                       // even (K % 128 == 0)
-    // per-lane LDS-DMA sources: half h (128 rows), instruction u (8 rows): row = 128 h + 16 wave + 8 u + lane / 8,
-    // LDS chunk position lane % 8 holds source chunk (lane % 8) ^ ((row >> 1) & 7)
-    const char* pa[4];
-    const char* pb[4];
+    // this wave's two instructions of a piece: 8 rows each.  X rows: wave rows 0-63 of wave row 0 (waves 0-3) / 1 (waves 4-7);
+    // B0 rows: 32 of each wave column, waves pair up on a column.  Y = X + 64 rows, B1 = B0 + 32 rows.
+    const char* px[2]; const char* py[2]; const char* pb0[2]; const char* pb1[2];
+    unsigned dx[2], db[2];                        // LDS byte offsets (inside the A / B region) of the X / B0 instructions
 #pragma unroll
-    for (int hu = 0; hu < 4; ++hu) {
-        const int row = (hu >> 1) * 128 + wave * 16 + (hu & 1) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        int ga = m0 + row, gb = n0 + row;
-        ga = ga < M ? ga : M - 1;                 // rows / columns past the edge: clamped, their outputs are never stored
-        gb = gb < N ? gb : N - 1;
-        pa[hu] = reinterpret_cast<const char*>(A + (long)ga * lda + c * 8);
-        pb[hu] = reinterpret_cast<const char*>(B + (long)gb * ldb + c * 8);
+    for (int u = 0; u < 2; ++u) {
+        const int rx = (wave < 4 ? 16 * wave : 128 + 16 * (wave - 4)) + 8 * u;         // first row of the 8-row group
+        const int ib = 16 * wave + 8 * u, rb = (ib >> 5) * 64 + (ib & 31);
+        dx[u] = (unsigned)rx * 128u;
+        db[u] = (unsigned)rb * 128u;
+        auto src = [&](const bf16_t* base, long ld, int r0, int R, int row) {
+            const int c = (lane & 7) ^ ((row >> 1) & 7);                             // LDS chunk position lane % 8 holds source chunk c
+            int gr = r0 + row;
+            gr = gr < R ? gr : R - 1;                                                // past the edge: clamped, never stored
+            return reinterpret_cast<const char*>(base + (long)gr * ld + c * 8);
+        };
+        px[u] = src(A, lda, m0, M, rx + (lane >> 3));
+        py[u] = src(A, lda, m0, M, rx + 64 + (lane >> 3));
+        pb0[u] = src(B, ldb, n0, N, rb + (lane >> 3));
+        pb1[u] = src(B, ldb, n0, N, rb + 32 + (lane >> 3));
     }
-    auto dma = [&](const char*& src, char* dst) {
-        __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst, 16, 0, 0);
-        src += 128;
+    auto dma = [&](const char*& s_, char* dst) {
+        __builtin_amdgcn_global_load_lds((gl_void*)s_, (lds_void*)dst, 16, 0, 0);
+        s_ += 128;
     };
-    // prologue: tile 0 (parity 0), then the B halves of tile 1 (parity 1)
+    // prologue: tile 0 (parity 0) in the order its phases need it, then what "phases 2 / 3 of tile -1" would have staged of tile 1
 #pragma unroll
-    for (int hu = 0; hu < 4; ++hu) dma(pa[hu], smem + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+    for (int u = 0; u < 2; ++u) dma(px[u], smem + dx[u]);
 #pragma unroll
-    for (int hu = 0; hu < 4; ++hu) dma(pb[hu], smem + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+    for (int u = 0; u < 2; ++u) dma(pb0[u], smem + BOFF + db[u]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dma(py[u], smem + dx[u] + 8192);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dma(pb1[u], smem + BOFF + db[u] + 4096);
     if (nkt > 1) {
 #pragma unroll
-        for (int hu = 0; hu < 4; ++hu) dma(pb[hu], smem + BUF + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+        for (int u = 0; u < 2; ++u) dma(pb0[u], smem + BUF + BOFF + db[u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) dma(px[u], smem + BUF + dx[u]);
         wait_vmcnt<4>();
     } else {
         wait_vmcnt<0>();
@@ -374,8 +404,8 @@ __device__ __forceinline__ void eight_phase_loop(f32x4 (&acc)[8][4], char* smem,
     const unsigned b_lo = BOFF + (unsigned)((wn * 64 + i) * 128) + sw;
     if (wm == 1) __builtin_amdgcn_s_barrier();    // waves 4-7 run one barrier behind
     for (int t = 0; t < nkt; t += 2) {
-        ep_tile<0>(acc, smem, pa, pb, a_lo, b_lo, wave, t + 1 < nkt, t + 2 < nkt);
-        ep_tile<1>(acc, smem, pa, pb, a_lo, b_lo, wave, t + 2 < nkt, t + 3 < nkt);
+        ep_tile<0>(acc, smem, px, py, pb0, pb1, dx, db, a_lo, b_lo, t + 1 < nkt, t + 2 < nkt);
+        ep_tile<1>(acc, smem, px, py, pb0, pb1, dx, db, a_lo, b_lo, t + 2 < nkt, t + 3 < nkt);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();    // balance the stagger
 }
@@ -404,7 +434,8 @@ constexpr unsigned F8_SCALE_OFF = 131072u;   // LDS: [parity][A 1 KiB | B 1 KiB]
 
 template <int PAR>
 __device__ __forceinline__ void ep8_tile(f32x4 (&acc)[8][4], char* smem, const char* __restrict__ A, const char* __restrict__ B,
-                                         const char* __restrict__ SA, const char* __restrict__ SB, unsigned (&oa)[4], unsigned (&ob)[4],
+                                         const char* __restrict__ SA, const char* __restrict__ SB, unsigned (&ox)[2], unsigned (&oy)[2],
+                                         unsigned (&ob0)[2], unsigned (&ob1)[2], const unsigned (&dx)[2], const unsigned (&db)[2],
                                          unsigned& osa, unsigned& osb, unsigned sa_step, unsigned sb_step, unsigned a_lo, unsigned b_lo,
                                          int wave, int lane, bool more1, bool more2) {
     constexpr unsigned BUF = 65536u, BOFF = 32768u;
@@ -426,13 +457,28 @@ __device__ __forceinline__ void ep8_tile(f32x4 (&acc)[8][4], char* smem, const c
         __builtin_amdgcn_global_load_lds((gl_void*)(base + off), (lds_void*)dst, 16, 0, 0);
         off += 128;
     };
+    // Staging by usage phase as in the bf16 loop (X / Y / B0 / B1 pieces, one per phase), plus the next tile's block scales, issued
+    // FIRST in phase 0 (their buffer was last read in phase 2 of the previous tile).  Stream order per tile:
+    //   P0: scales(t+1), Y(t+1)   P1: B1(t+1)   P2: B0(t+2)   P3: X(t+2)
+    // phase 0's wait retires B1(t) (vmcnt(8): B0(t+1), X(t+1), scales(t+1), Y(t+1) stay in flight), phase 3's retires X(t+1),
+    // B0(t+1) and scales(t+1) (vmcnt(8): Y(t+1), B1(t+1), B0(t+2), X(t+2) stay in flight).
     // ---- phase 0: A rows 0-63, B cols 0-31
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 0; x < 2; ++x) { b0f[x] = lds8(b_lo + x * 2048, b_hi + x * 2048); sb0[x] = scale(sc + 1024, wn * 64 + x * 16 + i); }
 #pragma unroll
     for (int x = 0; x < 4; ++x) { af[x] = lds8(a_lo + x * 2048, a_hi + x * 2048); sa[x] = scale(sc, wm * 128 + x * 16 + i); }
-    if (more1) { dma(A, oa[0], oth + (wave * 2) * 1024); dma(A, oa[1], oth + (wave * 2 + 1) * 1024); }
+    if (more1) {
+        if (lane < 8) {                       // this wave's 128 B of the next tile's A / B block scales (rows 32 wave .. +31)
+            __builtin_amdgcn_global_load_lds((gl_void*)(SA + osa), (lds_void*)(sc_o + wave * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gl_void*)(SB + osb), (lds_void*)(sc_o + 1024 + wave * 128), 16, 0, 0);
+        }
+        osa += sa_step; osb += sb_step;
+        dma(A, oy[0], oth + dx[0] + 8192); dma(A, oy[1], oth + dx[1] + 8192);
+        wait_vmcnt<8>();
+    } else {
+        wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -448,14 +494,7 @@ __device__ __forceinline__ void ep8_tile(f32x4 (&acc)[8][4], char* smem, const c
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 0; x < 2; ++x) { b1f[x] = lds8(b_lo + 4096 + x * 2048, b_hi + 4096 + x * 2048); sb1[x] = scale(sc + 1024, wn * 64 + 32 + x * 16 + i); }
-    if (more1) {
-        dma(A, oa[2], oth + 16384 + (wave * 2) * 1024); dma(A, oa[3], oth + 16384 + (wave * 2 + 1) * 1024);
-        if (lane < 8) {                       // this wave's 128 B of the next tile's A / B block scales (rows 32 wave .. +31)
-            __builtin_amdgcn_global_load_lds((gl_void*)(SA + osa), (lds_void*)(sc_o + wave * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gl_void*)(SB + osb), (lds_void*)(sc_o + 1024 + wave * 128), 16, 0, 0);
-        }
-        osa += sa_step; osb += sb_step;
-    }
+    if (more1) { dma(B, ob1[0], oth + BOFF + db[0] + 4096); dma(B, ob1[1], oth + BOFF + db[1] + 4096); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -471,6 +510,7 @@ __device__ __forceinline__ void ep8_tile(f32x4 (&acc)[8][4], char* smem, const c
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int x = 0; x < 4; ++x) { af[x] = lds8(a_lo + 8192 + x * 2048, a_hi + 8192 + x * 2048); sa[x] = scale(sc, wm * 128 + 64 + x * 16 + i); }
+    if (more2) { dma(B, ob0[0], cur + BOFF + db[0]); dma(B, ob0[1], cur + BOFF + db[1]); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -482,11 +522,12 @@ __device__ __forceinline__ void ep8_tile(f32x4 (&acc)[8][4], char* smem, const c
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 3: B of tile t+2 into THIS parity (its B rows were last read two phases ago); the one counted wait
+    // ---- phase 3: no fragment reads
     __builtin_amdgcn_sched_barrier(0);
     if (more2) {
-        dma(B, ob[0], cur + BOFF + (wave * 2) * 1024); dma(B, ob[1], cur + BOFF + (wave * 2 + 1) * 1024);
-        dma(B, ob[2], cur + BOFF + 16384 + (wave * 2) * 1024); dma(B, ob[3], cur + BOFF + 16384 + (wave * 2 + 1) * 1024);
+        dma(A, ox[0], cur + dx[0]); dma(A, ox[1], cur + dx[1]);
+        wait_vmcnt<8>();
+    } else if (more1) {
         wait_vmcnt<4>();
     } else {
         wait_vmcnt<0>();
@@ -510,16 +551,23 @@ __device__ __forceinline__ void eight_phase_loop_fp8(f32x4 (&acc)[8][4], char* s
                                                      int lane) {
     constexpr unsigned BUF = 65536u, BOFF = 32768u;
     const int nkt = K / 128;
-    unsigned oa[4], ob[4];
+    unsigned ox[2], oy[2], ob0[2], ob1[2], dx[2], db[2];
 #pragma unroll
-    for (int hu = 0; hu < 4; ++hu) {
-        const int row = (hu >> 1) * 128 + wave * 16 + (hu & 1) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        int ga = m0 + row, gb = n0 + row;
-        ga = ga < M ? ga : M - 1;
-        gb = gb < N ? gb : N - 1;
-        oa[hu] = (unsigned)((long)ga * lda + c * 16);
-        ob[hu] = (unsigned)((long)gb * ldb + c * 16);
+    for (int u = 0; u < 2; ++u) {
+        const int rx = (wave < 4 ? 16 * wave : 128 + 16 * (wave - 4)) + 8 * u;
+        const int ib = 16 * wave + 8 * u, rb = (ib >> 5) * 64 + (ib & 31);
+        dx[u] = (unsigned)rx * 128u;
+        db[u] = (unsigned)rb * 128u;
+        auto off = [&](long ld, int r0, int R, int row) {
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int gr = r0 + row;
+            gr = gr < R ? gr : R - 1;
+            return (unsigned)((long)gr * ld + c * 16);
+        };
+        ox[u] = off(lda, m0, M, rx + (lane >> 3));
+        oy[u] = off(lda, m0, M, rx + 64 + (lane >> 3));
+        ob0[u] = off(ldb, n0, N, rb + (lane >> 3));
+        ob1[u] = off(ldb, n0, N, rb + 32 + (lane >> 3));
     }
     // block scales: this wave's 32 rows of the tile, 4 rows (16 B) per lane of lanes 0-7; rows past the edge read the padding
     const char* SA = reinterpret_cast<const char*>(e.sa);
@@ -536,12 +584,18 @@ __device__ __forceinline__ void eight_phase_loop_fp8(f32x4 (&acc)[8][4], char* s
     }
     osa += sa_step; osb += sb_step;
 #pragma unroll
-    for (int hu = 0; hu < 4; ++hu) dma(A, oa[hu], smem + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+    for (int u = 0; u < 2; ++u) dma(A, ox[u], smem + dx[u]);
 #pragma unroll
-    for (int hu = 0; hu < 4; ++hu) dma(B, ob[hu], smem + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+    for (int u = 0; u < 2; ++u) dma(B, ob0[u], smem + BOFF + db[u]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dma(A, oy[u], smem + dx[u] + 8192);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) dma(B, ob1[u], smem + BOFF + db[u] + 4096);
     if (nkt > 1) {
 #pragma unroll
-        for (int hu = 0; hu < 4; ++hu) dma(B, ob[hu], smem + BUF + BOFF + (hu >> 1) * 16384 + (wave * 2 + (hu & 1)) * 1024);
+        for (int u = 0; u < 2; ++u) dma(B, ob0[u], smem + BUF + BOFF + db[u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) dma(A, ox[u], smem + BUF + dx[u]);
         wait_vmcnt<4>();
     } else {
         wait_vmcnt<0>();
@@ -553,8 +607,8 @@ __device__ __forceinline__ void eight_phase_loop_fp8(f32x4 (&acc)[8][4], char* s
     const unsigned b_lo = BOFF + (unsigned)((wn * 64 + i) * 128) + sw;
     if (wm == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nkt; t += 2) {
-        ep8_tile<0>(acc, smem, A, B, SA, SB, oa, ob, osa, osb, sa_step, sb_step, a_lo, b_lo, wave, lane, t + 1 < nkt, t + 2 < nkt);
-        ep8_tile<1>(acc, smem, A, B, SA, SB, oa, ob, osa, osb, sa_step, sb_step, a_lo, b_lo, wave, lane, t + 2 < nkt, t + 3 < nkt);
+        ep8_tile<0>(acc, smem, A, B, SA, SB, ox, oy, ob0, ob1, dx, db, osa, osb, sa_step, sb_step, a_lo, b_lo, wave, lane, t + 1 < nkt, t + 2 < nkt);
+        ep8_tile<1>(acc, smem, A, B, SA, SB, ox, oy, ob0, ob1, dx, db, osa, osb, sa_step, sb_step, a_lo, b_lo, wave, lane, t + 2 < nkt, t + 3 < nkt);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA results -> compiler-scheduled readers (the epilogue)
     if (wm == 0) __builtin_amdgcn_s_barrier();
