@@ -29,11 +29,16 @@ def _worker(rank, world, port, q):
         m._flat = FlatParams(m, torch.device("cpu"))
         m._ensure_engine = lambda: None               # CPU test: no engine, only the flat buffers + collectives
         red = FlatGradAllReducer(m, enc_chunk=2)
+        if rank == 1:                                 # state outside the flat buffers (the frozen position tables) is synced too
+            m.pos_encoding_encoder.data.add_(1.0)
         red.broadcast_parameters()
         flat = m._flat
         ref = flat.p32.clone()
         dist.broadcast(ref, 0)
         same_params = bool(torch.equal(ref, flat.p32))
+        tab = m.pos_encoding_encoder.data.clone()
+        dist.broadcast(tab, 0)
+        same_params = same_params and bool(torch.equal(tab, m.pos_encoding_encoder.data))
         g = torch.Generator().manual_seed(7 + rank)
         flat.g32.copy_(torch.randn(flat.n, generator=g))
         mine = flat.g32.clone()

@@ -1,0 +1,131 @@
+"""Two ranks on ONE GPU (gloo carries the collectives; RCCL refuses two ranks on a device): the real engine backward fires the
+section hooks, the bucketed averages run on device tensors while the rest of the backward computes, and the optimiser steps on
+the averaged flat buffer.  What the 8-GPU launch relies on, minus the transport: reference train.py:174-179 (Lightning DDP:
+parameter broadcast, gradient mean with equal rank weights, every rank normalising by its LOCAL target count)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, golden_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [os.path.dirname(here), here]
+        import synth
+        from test_jepa_gpu import SMALL, build, dev
+        from wavjepa_amd.trainer import StepRunner
+
+        def model(shift):
+            m, _ = build(SMALL, warmup_steps=2)
+            if shift:                      # rank 1 starts elsewhere (student, EMA teacher AND the frozen position tables): the
+                with torch.no_grad():      # broadcast has to bring all of it back
+                    for p in m.parameters():
+                        p.add_(0.01)
+            m.trainer.max_steps = 20
+            m.hparams["ema_decay"], m.hparams["ema_end_decay"], m.ema_end_step = 0.9, 0.99, 10
+            return m
+
+        m = model(rank == 1)
+        run = StepRunner(m)                                    # parameter broadcast + section hooks (JEPA: bucketed all-reduces)
+        assert run.reducer.active and run.sectioned and m._grads_ready_hook is not None
+        flat = m._flat
+        ref = flat.p32.clone()
+        dist.broadcast(ref, 0)
+        same_start = bool(torch.equal(ref, flat.p32))
+
+        fx = dict(np.load(os.path.join(golden_dir, "masks.npz")))
+
+        def batch(i):
+            sl = slice(2 * ((2 * i + rank) % 3), 2 * ((2 * i + rank) % 3) + 2)          # ranks see different clips and masks
+            audio = torch.from_numpy(synth.synth_audio(2, 1, 32159, seed=300 + 2 * i + rank)).to(torch.bfloat16).to(dev())
+            return (audio,) + tuple(torch.from_numpy(fx[k][sl]) for k in ("as_ctx", "as_tgt", "as_vis"))
+
+        # step 0 on a second, un-hooked replica of the broadcast weights: this rank's LOCAL gradient of the same batch
+        twin = model(False)
+        twin._ensure_engine()
+        twin._flat.p32.copy_(flat.p32)
+        twin._flat.t32.copy_(flat.t32)
+        twin._student_bf16_fresh = twin._teacher_bf16_fresh = False
+        twin.global_step = 0
+        out = twin.training_step(batch(0), 0)
+        out["loss"].backward()
+        local = twin._flat.g32.clone()
+        n_tgt = int(batch(0)[2].sum())
+        both = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        want = sum(both) / world
+
+        # the hooked model: forward, backward (hooks average the buckets as they complete), then look at the flat buffer
+        m.global_step = 0
+        out = m.training_step(batch(0), 0)
+        out["loss"].backward()
+        n_handles = len(run.reducer.handles)
+        run.reducer.wait()
+        torch.cuda.synchronize()
+        dev_grad = float((flat.g32 - want).norm() / (want.norm() + 1e-30))
+        from wavjepa_amd.ddp import section_ranges
+        per = {}
+        for tag, rs in section_ranges(flat, m.encoder.num_layers, run.reducer.enc_chunk).items():
+            for lo, hi in rs:
+                per[f"{tag}[{lo}:{hi}]"] = (float((flat.g32[lo:hi] - want[lo:hi]).norm() / (want[lo:hi].norm() + 1e-30)),
+                                            float((flat.g32[lo:hi] - local[lo:hi]).norm() / (local[lo:hi].norm() + 1e-30)))
+        print("rank", rank, "per-section (vs mean, vs local):", per, flush=True)
+        not_local = float((flat.g32 - local).norm() / (local.norm() + 1e-30))
+        run.optimizer.step()
+        run.scheduler.step()
+        m.global_step = 1
+        for i in (1, 2):                                        # two more whole steps through the same path
+            out = m.training_step(batch(i), i)
+            out["loss"].backward()
+            run.reducer.wait()
+            run.optimizer.step()
+            run.scheduler.step()
+            m.global_step = i + 1
+        torch.cuda.synchronize()
+        sums = torch.stack([flat.p32.double().sum(), flat.p32.double().abs().sum(), flat.t32.double().sum()]).cpu()
+        allsums = [torch.empty_like(sums) for _ in range(world)]
+        dist.all_gather(allsums, sums)
+        q.put((rank, same_start, n_handles, dev_grad, not_local, n_tgt, [s.tolist() for s in allsums], float(out["loss"].detach())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_average_gradients_and_stay_identical(golden_dir):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=560) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts = {}
+    for rank, same_start, n_handles, dev_grad, not_local, n_tgt, allsums, loss in res:
+        counts[rank] = n_tgt
+        assert same_start, f"rank {rank}: parameters differ from rank 0 after the broadcast"
+        assert n_handles >= 3, "the backward should have launched one collective per section (dec, enc:*, front)"
+        # two backward passes of the same batch differ by the fp32 summation order of the split-K weight gradients only
+        assert dev_grad < 1e-6, f"rank {rank}: averaged gradient deviates from the mean of the local gradients by {dev_grad}"
+        assert not_local > 1e-2, "the ranks' local gradients should differ (different clips): the average must not equal the local one"
+        assert allsums[0] == allsums[1], f"replicas diverged after three steps: {allsums}"
+        assert np.isfinite(loss)
+    assert counts[0] != counts[1], "the two ranks should hold different target counts (local normalisation is part of the contract)"

@@ -269,7 +269,13 @@ __global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restri
                 float y[4], x[TAPS];
                 conv4<TAPS>(y, x, w, xs, off, tl, g.stride);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = f2bf(gelu_f((y[j] - mu[j]) * rs[j] * ga[j] + be[j]));
+                for (int j = 0; j < 4; j += 2) {      // this pass is VALU-bound: erf-GELU on the packed fp32 pipe
+                    f32x2 z, gl, unused;
+                    z.x = (y[j] - mu[j]) * rs[j] * ga[j] + be[j];
+                    z.y = (y[j + 1] - mu[j + 1]) * rs[j + 1] * ga[j + 1] + be[j + 1];
+                    gelu_pk<false>(z, gl, unused);
+                    o[j] = f2bf(gl.x); o[j + 1] = f2bf(gl.y);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = f2bf(0.f);

@@ -942,8 +942,8 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                     // WJ_EPI_BIAS_GELU (forward only, e.C2 == NULL): C = gelu(h) and nothing else.
                     bf16x8 gl, gp;
                     if (e.q_out) {                                // kernel-uniform: MX fp8 of gelu(h) for the next GEMM (config 5)
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
+                        if (e.C2) gelu_bf16x8<true>(v, gl, gp);
+                        else gelu_bf16x8<false>(v, gl, gp);
                         float f[8], amax = 0.f;
 #pragma unroll
                         for (int x = 0; x < 8; ++x) { f[x] = bf2f(gl[x]); amax = fmaxf(amax, fabsf(f[x])); }
@@ -969,30 +969,17 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                                        s3 = __shfl(sbyte, base + 12, 64);
                         if ((lane & 15) == 0) e.q_scales[(long)(n >> 7) * e.ld_q + orow] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
                         if (e.C2) {                               // training form: gelu'(h) and the bf16 gelu(h) as well
-#pragma unroll
-                            for (int x = 0; x < 8; ++x) {
-                                float g0, g1;
-                                gelu_both_f(bf2f(v[x]), g0, g1);
-                                gp[x] = f2bf(g1);
-                            }
                             *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gp;
                             *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
                         } else if (e.C) {
                             *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gl;
                         }
                     } else if (e.C2) {                            // kernel-uniform
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) {
-                            float g0, g1;
-                            gelu_both_f(bf2f(v[x]), g0, g1);
-                            gl[x] = f2bf(g0);
-                            gp[x] = f2bf(g1);
-                        }
+                        gelu_bf16x8<true>(v, gl, gp);
                         *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gp;
                         *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = gl;
                     } else {
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) gl[x] = f2bf(gelu_f(bf2f(v[x])));
+                        gelu_bf16x8<false>(v, gl, gp);
                         *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = gl;
                     }
                 } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
@@ -1006,11 +993,12 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                     }
                 } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
                     const bool valid = (m % e.seg_rows) < e.seg_valid;
-                    bf16x8 pre, post;
+                    bf16x8 pre, post, unused;
+                    gelu_bf16x8<false>(v, post, unused);
 #pragma unroll
                     for (int x = 0; x < 8; ++x) {
                         pre[x] = valid ? v[x] : f2bf(0.f);
-                        post[x] = valid ? f2bf(gelu_f(bf2f(v[x]))) : f2bf(0.f);
+                        post[x] = valid ? post[x] : f2bf(0.f);
                     }
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = pre;
                     *reinterpret_cast<bf16x8*>((bf16_t*)e.C2 + off) = post;
