@@ -396,6 +396,27 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
     assert line["config"]["global_batch"] == 16
 
 
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """The N = 2 launch of the bench end to end on the 1-GPU box: RCCL refuses two ranks on one device, so the collectives go over
+    gloo (WJ_DIST_BACKEND, a development switch of init_distributed); everything else -- per-rank sources, broadcast, bucketed
+    averages from the backward's hooks, max-over-ranks timing, whole-job value, the replica checksum -- is the driver's path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--clips-per-gpu", "16",
+           "--dense-steps", "0", "--no-cpu-baseline", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["replicas_equal"] is True and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 32 and line["config"]["parallelism"] == "dp2"
+    assert abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]      # whole-job clips/s over the slowest rank's time
+
+
 @pytest.mark.parametrize("stacks,ragged", [("own", True), ("shared", True), ("own", False)])
 def test_forward_backward_parity_channel_extractor(stacks, ragged):
     """ConvChannelFeatureExtractor (reference extractors/audio_channel_feature_extractor.py:154-179; WavJEPA-Nat, BASELINE config

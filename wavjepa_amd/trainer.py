@@ -15,16 +15,25 @@ from .ddp import FlatGradAllReducer
 
 
 def init_distributed() -> tuple:
-    """(rank, local_rank, world).  RCCL ("nccl" backend on ROCm) when launched by torch.distributed.run."""
+    """(rank, local device index, world).  RCCL ("nccl" backend on ROCm) when launched by torch.distributed.run.
+
+    WJ_DIST_BACKEND=gloo is a development aid: RCCL refuses two ranks on one device, gloo does not, so a 1-GPU box can run the
+    N-rank launch end to end (ranks then share the visible GPUs round-robin; the compute path is unchanged)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # started by torch.distributed.run (any world size)
+    backend = os.environ.get("WJ_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     if launched and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, local, world
