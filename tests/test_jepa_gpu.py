@@ -745,6 +745,50 @@ def test_hear_runtime_timestamp_embeddings_vs_oracle():
         assert scene.shape == (2, 768) and rel(scene, ref.mean(1)) < 2e-2
 
 
+def test_trainer_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """Checkpoint / resume (reference train.py:244 `trainer.fit(..., ckpt_path=...)`; Lightning checkpoint keys): six steps straight
+    through against three steps, a checkpoint, and a NEW process-like start (differently initialised model, fresh optimiser and
+    scheduler) that resumes from it for the last three.  Parameters, EMA teacher, AdamW moments, step counter and learning rate
+    must land on the same values (the weight gradients' split-K sums are the only order-dependent arithmetic: 1e-5)."""
+    from wavjepa_amd.data import SyntheticAudioSource
+    from wavjepa_amd.masking import TimeInverseBlockMasker
+    from wavjepa_amd.trainer import Trainer
+
+    def source():
+        return SyntheticAudioSource(TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1), batch_size=2, samples_per_audio=2, n_tokens=200,
+                                    seconds=3.0, seed=11, n_mask_sets=4, device=dev())
+
+    mask_sets = source().mask_sets             # the masker draws from OS entropy (as upstream): one set of masks for both runs
+
+    def loader(skip):
+        src = source()
+        src.mask_sets = mask_sets
+        i = 0
+        while True:
+            b = src.next_batch()
+            torch.manual_seed(1000 + i)        # the crop offsets of on_after_batch_transfer come from the global generator
+            if i >= skip:
+                yield b
+            i += 1
+
+    def run(seed, root, ckpt=None, skip=0):
+        m, _ = build(SMALL, seed=seed, warmup_steps=2)
+        tr = Trainer(max_steps=6, default_root_dir=str(root), checkpoint_every_n_steps=3, log_every_n_steps=0)
+        return m, tr.fit(m, train_dataloaders=loader(skip), ckpt_path=ckpt)
+
+    ma, ra = run(7, tmp_path / "a")
+    ck = tmp_path / "a" / "step=3.ckpt"
+    assert ck.exists() and (tmp_path / "a" / "last.ckpt").exists()
+    saved = torch.load(ck, map_location="cpu", weights_only=False)
+    assert saved["global_step"] == 3 and {"state_dict", "hyper_parameters", "optimizer", "lr_scheduler"} <= set(saved)
+    mb, rb = run(8, tmp_path / "b", ckpt=str(ck), skip=3)
+    assert ma.global_step == mb.global_step == 6 and ra.optimizer._t == rb.optimizer._t == 6
+    assert ra.scheduler.get_last_lr() == rb.scheduler.get_last_lr()
+    for name, a, b in (("student", ma._flat.p32, mb._flat.p32), ("teacher", ma._flat.t32, mb._flat.t32),
+                       ("adam_m", ma._flat.adam_m, mb._flat.adam_m), ("adam_v", ma._flat.adam_v, mb._flat.adam_v)):
+        assert rel(a, b) < 1e-5, (name, rel(a, b))
+
+
 def test_state_dict_roundtrip_and_reference_checkpoint_layout():
     m, P = build(SMALL)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
