@@ -38,6 +38,7 @@ class RuntimeJEPA(torch.nn.Module):
     def __init__(self, in_channels, weights, is_spectrogram, process_seconds, extractor, model_size, sr, **kwargs) -> None:
         super().__init__()
         self.sample_rate = sr
+        self.in_channels = int(in_channels)
         self.model = JEPA(feature_extractor=extractor, transformer_encoder_cfg=TransformerEncoderCFG.create(),
                           transformer_encoder_layers_cfg=TransformerLayerCFG.create(), transformer_decoder_cfg=TransformerEncoderCFG.create(),
                           transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384), resample_sr=self.sample_rate,
@@ -48,11 +49,20 @@ class RuntimeJEPA(torch.nn.Module):
         self.scene_embedding_size = self.embedding_size
         self.timestamp_embedding_size = self.embedding_size
         self.unit_frames = int(process_seconds * self.sample_rate)
-        self.output_steps = self.model.extract_audio.total_patches(self.unit_frames)
+        self.output_steps = self.steps_per_window(self.model.extract_audio.total_patches(self.unit_frames))
         if torch.cuda.is_available():
             self.model.cuda()
         self.model.eval()
         self.feature_extractor = FeatureExtractor(in_channels=in_channels)
+
+    # the two points where the multi-channel runtime (runtime_natjepa.py) differs from this one
+    def steps_per_window(self, window_tokens: int) -> int:
+        """Embedding steps one window contributes to the output (here: every token of the window)."""
+        return window_tokens
+
+    def window_embedding(self, window: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """[B, C, unit_frames] + key-padding mask over the window's `output_steps` -> [B, output_steps, D]."""
+        return self.model.get_audio_representation(normalize(window), mask)
 
     def to_feature(self, batch_audio):
         return self.feature_extractor(batch_audio)
@@ -81,7 +91,7 @@ class RuntimeJEPA(torch.nn.Module):
             mask = padding_mask[..., mask_idx:mask_idx + self.output_steps]
             if mask.shape[-1] < self.output_steps:
                 mask = torch.nn.functional.pad(mask, (0, self.output_steps - mask.shape[-1]), value=True)
-            embeddings.append(self.model.get_audio_representation(normalize(window), mask))
+            embeddings.append(self.window_embedding(window, mask))
             mask_idx += self.output_steps
         x = torch.hstack(embeddings)[:, :cut_off, :]
         ts = get_timestamps(self.sample_rate, B, input_audio_len, x)

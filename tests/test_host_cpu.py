@@ -327,6 +327,18 @@ def test_hear_runtime_padding_arithmetic():
     assert set(sd) == {"encoder.layers.0.linear1.weight", "mask_token"}
 
 
+def test_hear_config_modules_follow_the_hear_contract():
+    """hear_configs/*.py (reference hear_configs/WavJEPA.py:11-43, WavJEPA_w2v2.py:11-45): `load_model` builds the runtime without
+    weights, window length and steps per window follow the conv spec (2.01 s -> 200 steps; 7-layer spec on 4.02 s -> 200 steps)."""
+    import hear_configs.WavJEPA as base
+    import hear_configs.WavJEPA_w2v2 as w2v2
+    for mod, unit, steps in ((base, int(2.01 * 16000), 200), (w2v2, int(4.02 * 16000), 200)):      # 32159 / 64319 (float product)
+        assert callable(mod.get_scene_embeddings) and callable(mod.get_timestamp_embeddings) and mod.SR == 16000
+        rt = mod.load_model()
+        assert rt.unit_frames == unit and rt.output_steps == steps and rt.sample_rate == 16000
+        assert rt.scene_embedding_size == rt.timestamp_embedding_size == 768
+
+
 def test_mask_plan_takes_group_count_from_the_masks_and_validates_shapes():
     """reference jepa.py:402-405: nr_targets = target_indices.shape[1]; a mismatch must raise, never index out of bounds."""
     import pytest

@@ -745,6 +745,39 @@ def test_hear_runtime_timestamp_embeddings_vs_oracle():
         assert scene.shape == (2, 768) and rel(scene, ref.mean(1)) < 2e-2
 
 
+def test_hear_nat_runtime_timestamp_embeddings_vs_oracle():
+    """Multi-channel HEAR wrapper (reference hear_api/runtime_natjepa.py:90-93,139-147): a 2-channel clip through the channel
+    extractor's two token streams per 2.01 s window; the padded-step key mask repeated per stream; embedding = mean over the streams;
+    cut-off and timestamps as in the mono wrapper.  Base model, against the oracle's restatement (CPU, fp32); a mono clip is
+    duplicated to both channels by the feature helper."""
+    from hear_api.runtime_natjepa import RuntimeNatJEPA
+    from oracle import hear_oracle as HO
+    from wavjepa_amd.extractors import ConvChannelFeatureExtractor
+    ext = ConvChannelFeatureExtractor(conv_layers_spec=list(J.WAVJEPA_CONV_SPEC), in_channels=2, share_weights_over_channels=False)
+    rt = RuntimeNatJEPA(in_channels=2, weights=None, is_spectrogram=False, process_seconds=2.01, extractor=ext, model_size="base", sr=16000)
+    assert rt.output_steps == 200 and rt.model.total_patches == 400 and rt.scene_embedding_size == 768
+    own = rt.model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in own.items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=41).items()}
+    for k in ("pos_encoding_encoder", "pos_encoding_decoder"):
+        sd[k] = own[k].detach().cpu().clone()
+    rt.model.load_state_dict(sd)
+    wave = torch.from_numpy(synth.synth_audio(2, 2, 40000, seed=77)).float()                      # [B, 2, n]: 2 windows, 1.2 of them audio
+    emb, ts = rt.get_timestamp_embeddings(wave)
+    feats = rt.to_feature(wave).cpu()
+    assert feats.shape == (2, 2, 40000)
+    ref, ref_ts = HO.timestamp_embeddings(sd, feats, mode="fp32", channel_streams=2)
+    assert emb.shape == ref.shape == (2, ref.shape[1], 768) and 200 < ref.shape[1] < 400 and ts.shape == ref_ts.shape
+    assert torch.allclose(ts.cpu(), ref_ts, atol=1e-3)
+    assert rel(emb, ref) < 2e-2, rel(emb, ref)
+    scene = rt.get_scene_embeddings(wave)
+    assert scene.shape == (2, 768) and rel(scene, ref.mean(1)) < 2e-2
+    mono = rt.to_feature(wave[:, 0])                                                                # [B, n] -> both channels
+    assert mono.shape == (2, 2, 40000) and torch.equal(mono[:, 0], mono[:, 1])
+    with pytest.raises(ValueError):
+        RuntimeNatJEPA(in_channels=4, weights=None, is_spectrogram=False, process_seconds=2.01, extractor=ext, model_size="base", sr=16000)
+
+
 def test_trainer_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     """Checkpoint / resume (reference train.py:244 `trainer.fit(..., ckpt_path=...)`; Lightning checkpoint keys): six steps straight
     through against three steps, a checkpoint, and a NEW process-like start (differently initialised model, fresh optimiser and
