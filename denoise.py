@@ -11,6 +11,7 @@ import sys
 
 import torch
 
+from utils import checkpoint_dir, get_identity_from_cfg_denoise
 from wavjepa_amd.config import load_config, parse_conv_spec
 from wavjepa_amd.data_modules import WebAudioDataModuleDenoiser
 from wavjepa_amd.denoiser import Denoiser
@@ -40,11 +41,11 @@ class ComponentFactory:
 
 
 def setup_trainer(cfg) -> Trainer:
-    identity = f"Data={cfg.data.name}/Alpha={cfg.trainer.alpha}/BatchSize={cfg.trainer.batch_size}/NrGPUs={cfg.trainer.num_gpus}"
     return Trainer(accelerator=cfg.trainer.accelerator, max_epochs=cfg.trainer.epochs, max_steps=cfg.trainer.steps,
                    precision=cfg.trainer.precision, devices=int(cfg.trainer.num_gpus), gradient_clip_val=1.0, gradient_clip_algorithm="norm",
                    log_every_n_steps=cfg.trainer.get("log_every_n_steps", 1),
-                   default_root_dir=os.path.join(cfg.save_dir, "saved_models_jepa_denoised", identity), checkpoint_every_n_steps=2500)
+                   default_root_dir=checkpoint_dir(cfg, "saved_models_jepa_denoised", get_identity_from_cfg_denoise(cfg)),
+                   checkpoint_every_n_steps=2500)
 
 
 def create_data_module(cfg, nr_patches, rank: int):

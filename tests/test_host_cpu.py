@@ -327,6 +327,24 @@ def test_hear_runtime_padding_arithmetic():
     assert set(sd) == {"encoder.layers.0.linear1.weight", "mask_token"}
 
 
+def test_run_identity_strings_equal_the_reference_output():
+    """utils.get_identity_from_cfg(_denoise) (reference utils.py:1-43): the checkpoint directory of a configuration.  Expected strings
+    = what the reference's own functions return for these configurations (generated in the build container by importing
+    /root/reference/utils.py on the same config objects)."""
+    import utils
+    from wavjepa_amd.config import load_config
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
+    cfg = load_config(root, [])
+    want = ("Data=Synthetic_Extractor=wavjepa_InSeconds=2.01_BatchSize=32_NrSamples=8_NrGPUs=1_LR=0.0004_TargetProb=0.25_TargetLen=10_"
+            "ContextProb=0.65_ContextLen=10_MinContextBlock=1_ContextRatio=0.1")
+    assert utils.get_identity_from_cfg(cfg) == want
+    assert utils.checkpoint_dir(cfg, "saved_models_jepa_new_masking", want).endswith(
+        "/saved_models_jepa_new_masking/Data=Synthetic/Extractor=wavjepa/InSeconds=2.01/BatchSize=32/NrSamples=8/NrGPUs=1/LR=0.0004/"
+        "TargetProb=0.25/TargetLen=10/ContextProb=0.65/ContextLen=10/MinContextBlock=1/ContextRatio=0.1")
+    cfgd = load_config(root, [], config_name="denoise")
+    assert utils.get_identity_from_cfg_denoise(cfgd) == "Data=AudioSet_Extractor=wavjepa_InSeconds=2.01_BatchSize=32_NrSamples=8_NrGPUs=1_LR=0.0001_Alpha=0.0"
+
+
 def test_hear_config_modules_follow_the_hear_contract():
     """hear_configs/*.py (reference hear_configs/WavJEPA.py:11-43, WavJEPA_w2v2.py:11-45): `load_model` builds the runtime without
     weights, window length and steps per window follow the conv spec (2.01 s -> 200 steps; 7-layer spec on 4.02 s -> 200 steps)."""

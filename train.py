@@ -13,6 +13,7 @@ import sys
 
 import torch
 
+from utils import checkpoint_dir, get_identity_from_cfg
 from wavjepa_amd.config import load_config, parse_conv_spec
 from wavjepa_amd.data import SyntheticAudioSource
 from wavjepa_amd.extractors import ConvFeatureExtractor, Extractor
@@ -76,7 +77,8 @@ def setup_trainer(cfg) -> Trainer:
                    precision=cfg.trainer.precision, devices=int(cfg.trainer.num_gpus), gradient_clip_val=5,
                    gradient_clip_algorithm="norm", strategy="ddp" if int(cfg.trainer.num_gpus) > 1 else "auto",
                    log_every_n_steps=cfg.trainer.get("log_every_n_steps", 50),
-                   default_root_dir=os.path.join(cfg.save_dir, "saved_models_jepa"))
+                   checkpoint_every_n_steps=25000,      # ModelCheckpoint(every_n_train_steps=25000, save_last=True), reference train.py:146-153
+                   default_root_dir=checkpoint_dir(cfg, "saved_models_jepa_new_masking", get_identity_from_cfg(cfg)))
 
 
 def build_model(cfg):
