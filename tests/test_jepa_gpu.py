@@ -717,6 +717,17 @@ def test_inference_representation(golden_dir):
     rep = m.get_audio_representation(audio, pad.to(dev()))
     ref = J.audio_representation(P, audio.to(torch.bfloat16), pad.to(dev()), spec=SMALL_SPEC, enc_heads=2, mode="bf16")
     assert rep.shape == (2, 200, 128) and rel(rep[:, :150], ref[:, :150]) < 1e-2
+    # state loaded AFTER the engine exists -- weights and the frozen position table -- reaches the kernels
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["pos_encoding_encoder"] = sd["pos_encoding_encoder"] * 0.5
+    sd["encoder.layers.0.linear1.weight"] = sd["encoder.layers.0.linear1.weight"] * 1.25
+    m.load_state_dict(sd)
+    P2 = dict(P)
+    P2["pos_encoding_encoder"] = P["pos_encoding_encoder"] * 0.5
+    P2["encoder.layers.0.linear1.weight"] = P["encoder.layers.0.linear1.weight"] * 1.25
+    rep2 = m.get_audio_representation(audio, pad.to(dev()))
+    ref2 = J.audio_representation(P2, audio.to(torch.bfloat16), pad.to(dev()), spec=SMALL_SPEC, enc_heads=2, mode="bf16")
+    assert rel(rep2[:, :150], ref2[:, :150]) < 1e-2 and rel(rep2[:, :150], ref[:, :150]) > 5e-2
 
 
 def test_hear_runtime_timestamp_embeddings_vs_oracle():

@@ -70,16 +70,12 @@ class FlatGradAllReducer:
         if flat.tn > 0:
             dist.broadcast(flat.t32, 0, group=self.pg)
         # module state outside the two flat buffers (the fixed sin-cos position tables: requires_grad=False parameters, and any
-        # buffer): DDP's constructor syncs those from rank 0 too.  In place -- the engine reads the tables through these storages.
+        # buffer): DDP's constructor syncs those from rank 0 too.  In place -- the engine reads the tables through these storages (or
+        # refreshes its converted copy in prepare_weights).
         owned = set(flat.by_name) | set(flat.tby_name)
         rest = [(n, t) for n, t in list(self.module.named_parameters()) + list(self.module.named_buffers()) if n not in owned]
         for _, t in sorted(rest, key=lambda nt: nt[0]):
             dist.broadcast(t.data, 0, group=self.pg)
-        eng = getattr(self.module, "_engine", None)
-        for attr, name in (("pos_enc", "pos_encoding_encoder"), ("pos_dec", "pos_encoding_decoder")):
-            tab = getattr(self.module, name, None)
-            if eng is not None and tab is not None and hasattr(eng, attr) and getattr(eng, attr).data_ptr() != tab.data_ptr():
-                getattr(eng, attr).copy_(tab.data.reshape(getattr(eng, attr).shape))     # the engine holds a converted copy
         self.module._student_bf16_fresh = False
         self.module._teacher_bf16_fresh = False
 

@@ -226,6 +226,9 @@ class JepaEngine:
         self.dev = flat.device
         self.pos_enc = pos_enc.reshape(-1, cfg.d_enc).contiguous().float().to(self.dev)
         self.pos_dec = pos_dec.reshape(-1, cfg.d_dec).contiguous().float().to(self.dev)
+        # fp32 tables on this device are used in place (load_state_dict / the data-parallel broadcast write through); a converted copy
+        # (other dtype or device) is refreshed from its source in prepare_weights
+        self._pos_src = (pos_enc, pos_dec)
         self.L, self.P = conv_geometry(cfg.n_samples, cfg.conv_spec)
         self.S = max(1, int(cfg.streams))            # channel streams through mono conv stacks
         self.Tc = self.L[-1]                         # conv frames per stream
@@ -364,6 +367,9 @@ class JepaEngine:
     def prepare_weights(self, force_cast: bool = False) -> None:
         """bf16 shadow copies (when stale) + the GEMM layouts of conv layers 1.. from the fp32 masters."""
         f = self.flat
+        for mine, src in zip((self.pos_enc, self.pos_dec), self._pos_src):
+            if mine.data_ptr() != src.data_ptr():
+                mine.copy_(src.reshape(mine.shape))
         if force_cast or not f.bf16_fresh:
             ops.cast_f32_to_bf16(f.p32, f.p16, f.n)
             if f.tn > 0:
