@@ -235,8 +235,10 @@ def test_train_py_runs_on_flac_shards(tmp_path):
             tf.addfile(ti, io.BytesIO(data))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "train.py"), "data=audioset", f"data.data_dirs={shard}", "trainer.batch_size=2", "trainer.steps=3",
-           "trainer.log_every_n_steps=1"]
+           "trainer.log_every_n_steps=1", f"save_dir={tmp_path / 'runs'}"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     losses = [float(ln.split("loss")[1].split()[0]) for ln in r.stdout.splitlines() if ln.startswith("step ")]
     assert len(losses) >= 3 and all(np.isfinite(losses)), r.stdout[-1500:]
+    ckpts = list((tmp_path / "runs" / "saved_models_jepa_new_masking").rglob("last.ckpt"))       # the reference's run-identity directory
+    assert len(ckpts) == 1 and "Data=AudioSet" in str(ckpts[0]) and "BatchSize=2" in str(ckpts[0])
