@@ -73,7 +73,8 @@ def group_of(name):
     return "other"
 
 
-@pytest.mark.parametrize("cfg_name,n,ragged", [("small", 4, True), ("small", 4, False), ("base", 2, True), ("base", 2, False)])
+@pytest.mark.parametrize("cfg_name,n,ragged", [("small", 4, True), ("small", 4, False), ("small", 1, True), ("small", 1, False),
+                                                ("base", 2, True), ("base", 2, False)])      # n = 1: a single clip (fewer rows than one GEMM tile)
 def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     """ragged = visible-token execution (the default); dense = the reference's key-masked full-length shapes.  Both must
     give the oracle's loss, outputs and gradients."""
