@@ -126,6 +126,28 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
         assert e < 3e-2, (g, e)
 
 
+def test_batch_size_changes_between_steps(golden_dir):
+    """A loader's last, shorter batch: the arena follows the clip count (4 -> 2 -> 4 clips on one model); every forward / backward must
+    equal what a fresh model gives for that batch."""
+    m, P = build(SMALL)
+    ctx, tgt, vis = masks(golden_dir, 4)
+
+    def step(model, n):
+        audio = torch.from_numpy(synth.synth_audio(n, 1, 32159, seed=60 + n)).to(torch.bfloat16).to(dev())
+        out = model(audio, ctx[:n], tgt[:n], vis[:n])
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        return float(out["loss"].detach()), model._flat.g32.clone()
+
+    l4, g4 = step(m, 4)
+    l2, g2 = step(m, 2)
+    l4b, g4b = step(m, 4)
+    f2, fg2 = step(build(SMALL)[0], 2)
+    assert abs(l2 - f2) < 1e-6 * abs(f2) and rel(g2, fg2) < 1e-5, (l2, f2, rel(g2, fg2))
+    assert abs(l4 - l4b) < 1e-6 * abs(l4) and rel(g4b, g4) < 1e-5, (l4, l4b, rel(g4b, g4))
+    assert abs(l4 - l2) > 1e-4 * abs(l4)
+
+
 def test_stock_pytorch_autocast_yardstick_base_model(golden_dir):
     """SURVEY 3.2 / north star ("encoder outputs within 1e-3 rel in bf16"): what does PyTorch's OWN bf16 autocast on this GPU do to the
     same model?  The oracle's fp32 code path is run under `torch.autocast("cuda", dtype=torch.bfloat16)` -- PyTorch's cast policy on
