@@ -1,7 +1,19 @@
-"""HEAR-2021 API wrapper around the MI355X JEPA module (same surface as reference hear_api/runtime.py:12-155:
-`RuntimeJEPA(...).get_timestamp_embeddings(audio)`, `get_scene_embeddings`, attributes `sample_rate`,
-`scene_embedding_size`, `timestamp_embedding_size`)."""
+"""HEAR-2021 API wrapper around the MI355X JEPA module.  Surface of reference hear_api/runtime.py:12-155:
+`RuntimeJEPA(...).get_timestamp_embeddings(audio)` / `get_scene_embeddings(audio)`, attributes `sample_rate`,
+`scene_embedding_size`, `timestamp_embedding_size`, and the module-level helpers `normalize`, `calculate_padding_mask`,
+`get_timestamps`.
+
+How a clip becomes embeddings (same arithmetic as upstream, organised around a window plan):
+  1. loudness-normalise and fix the channel count (feature_helper), zero-pad up to the next multiple of the window length (a clip
+     that already is a multiple gets one more, all-padding window, as upstream);
+  2. every window is normalised on its own and encoded with a key-padding mask over the embedding steps that lie in the padding;
+  3. windows are concatenated and cut at the first padded step; step i is stamped  i * clip_seconds / n_steps  (ms).
+Upstream computes the number of mask windows with INTEGER seconds (`target_length // sr`: 2 for 2.01 s windows), so the mask can
+be longer or shorter than the window grid; that is kept (`WindowPlan.key_mask` is cut / extended with `True`)."""
 from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
 
 import torch
 
@@ -12,21 +24,27 @@ from .feature_helper import FeatureExtractor
 
 
 def normalize(audio: torch.Tensor) -> torch.Tensor:
-    mean = audio.mean(dim=(-2, -1), keepdim=True)
-    std = audio.std(dim=(-2, -1), keepdim=True)
-    return (audio - mean) / (std + 1e-5)
+    """Zero mean, unit (unbiased) deviation over channels x time of every window."""
+    centred = audio - audio.mean(dim=(-2, -1), keepdim=True)
+    return centred / (audio.std(dim=(-2, -1), keepdim=True) + 1e-5)
 
 
 def calculate_padding_mask(pad_frames, total_frames, sr, output_steps, process_seconds, model, B):
-    """Key-padding mask over the token grid of all windows + the cut-off index (reference runtime.py:19-35, including
-    its integer-seconds arithmetic)."""
-    n_chunks = int((total_frames / sr) / process_seconds)
-    total_output_steps = output_steps * n_chunks
-    mask = torch.zeros((B, total_output_steps), dtype=torch.bool, device=model.device)
-    output_sr = int(output_steps / process_seconds)
-    pad_steps = int((pad_frames / sr) * output_sr)
-    mask[..., total_output_steps - pad_steps:] = True
-    return mask, total_output_steps - pad_steps
+    """(mask [B, steps] with True on the steps that fall into the trailing padding, index of the first such step).
+    `steps` = output_steps x the number of `process_seconds` chunks in the padded clip; the padded tail, converted to steps at
+    int(output_steps / process_seconds) steps per second, is what gets masked (reference runtime.py:19-35)."""
+    steps = output_steps * int(total_frames / sr / process_seconds)
+    first_padded = steps - int(pad_frames / sr * int(output_steps / process_seconds))
+    start = first_padded if first_padded >= 0 else max(steps + first_padded, 0)       # upstream writes mask[..., first_padded:] = True
+    mask = (torch.arange(steps, device=model.device) >= start).expand(B, steps).clone()
+    return mask, first_padded
+
+
+def get_timestamps(sample_rate, B, input_audio_len, x):
+    """Start time in ms of every embedding step: the clip's duration spread evenly over the steps (reference runtime.py:145-155)."""
+    n_steps = x.shape[1]
+    step_ms = input_audio_len / sample_rate / n_steps * 1000
+    return torch.tensor([step_ms * i for i in range(n_steps)]).unsqueeze(0).repeat(B, 1)
 
 
 def strip_compile_prefixes(state_dict):
@@ -34,21 +52,27 @@ def strip_compile_prefixes(state_dict):
     return {k.replace("._orig_mod", ""): v for k, v in state_dict.items()}
 
 
+@dataclass
+class WindowPlan:
+    pad_frames: int          # zeros appended to the clip
+    n_windows: int
+    cut_off: int             # embedding steps kept
+    key_masks: List[torch.Tensor]     # per window: [B, steps_per_window] bool, True = padded step
+
+
 class RuntimeJEPA(torch.nn.Module):
     def __init__(self, in_channels, weights, is_spectrogram, process_seconds, extractor, model_size, sr, **kwargs) -> None:
         super().__init__()
         self.sample_rate = sr
         self.in_channels = int(in_channels)
-        self.model = JEPA(feature_extractor=extractor, transformer_encoder_cfg=TransformerEncoderCFG.create(),
-                          transformer_encoder_layers_cfg=TransformerLayerCFG.create(), transformer_decoder_cfg=TransformerEncoderCFG.create(),
-                          transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384), resample_sr=self.sample_rate,
-                          size=model_size, process_audio_seconds=process_seconds)
+        layer, stack = TransformerLayerCFG.create, TransformerEncoderCFG.create
+        self.model = JEPA(feature_extractor=extractor, transformer_encoder_cfg=stack(), transformer_encoder_layers_cfg=layer(),
+                          transformer_decoder_cfg=stack(), transformer_decoder_layers_cfg=layer(d_model=384),
+                          resample_sr=sr, size=model_size, process_audio_seconds=process_seconds)
         if weights is not None:
             self.model.load_state_dict(strip_compile_prefixes(weights["state_dict"]), strict=False)
-        self.embedding_size = self.model.encoder_embedding_dim
-        self.scene_embedding_size = self.embedding_size
-        self.timestamp_embedding_size = self.embedding_size
-        self.unit_frames = int(process_seconds * self.sample_rate)
+        self.embedding_size = self.scene_embedding_size = self.timestamp_embedding_size = self.model.encoder_embedding_dim
+        self.unit_frames = int(process_seconds * sr)
         self.output_steps = self.steps_per_window(self.model.extract_audio.total_patches(self.unit_frames))
         if torch.cuda.is_available():
             self.model.cuda()
@@ -67,41 +91,29 @@ class RuntimeJEPA(torch.nn.Module):
     def to_feature(self, batch_audio):
         return self.feature_extractor(batch_audio)
 
-    def get_scene_embeddings(self, audio):
-        embeddings, _ = self.get_timestamp_embeddings(audio)
-        return torch.mean(embeddings, dim=1)
+    def window_plan(self, n_frames: int, B: int) -> WindowPlan:
+        pad = self.unit_frames - n_frames % self.unit_frames            # a full extra window when n_frames is a multiple
+        total = n_frames + pad
+        mask, cut = calculate_padding_mask(pad_frames=pad, total_frames=total, sr=self.sample_rate, output_steps=self.output_steps,
+                                           process_seconds=self.model.target_length // self.sample_rate, model=self.model, B=B)
+        n_windows, S = total // self.unit_frames, self.output_steps
+        if mask.shape[-1] < n_windows * S:                              # integer-seconds chunk count fell short of the window grid
+            mask = torch.nn.functional.pad(mask, (0, n_windows * S - mask.shape[-1]), value=True)
+        return WindowPlan(pad, n_windows, cut, [mask[:, w * S:(w + 1) * S] for w in range(n_windows)])
 
     def get_timestamp_embeddings(self, audio):
-        B = audio.shape[0]
-        audio = self.to_feature(audio)
-        input_audio_len = audio.shape[-1]
-        if audio.ndim != 3:
+        feats = self.to_feature(audio)
+        if feats.ndim != 3:
             raise ValueError("audio input tensor must be 2D with shape (n_sounds, n_channels, num_samples)")
-        cur_frames = audio.shape[-1]
-        pad_frames = self.unit_frames - (cur_frames % self.unit_frames)
-        if pad_frames > 0:
-            audio = torch.nn.functional.pad(audio, (0, pad_frames), mode="constant")
-        padding_mask, cut_off = calculate_padding_mask(pad_frames=pad_frames, total_frames=audio.shape[-1], sr=self.sample_rate,
-                                                       output_steps=self.output_steps,
-                                                       process_seconds=self.model.target_length // self.sample_rate,
-                                                       model=self.model, B=B)
-        embeddings, mask_idx = [], 0
-        for i in range(audio.shape[-1] // self.unit_frames):
-            window = audio[..., i * self.unit_frames:(i + 1) * self.unit_frames]
-            mask = padding_mask[..., mask_idx:mask_idx + self.output_steps]
-            if mask.shape[-1] < self.output_steps:
-                mask = torch.nn.functional.pad(mask, (0, self.output_steps - mask.shape[-1]), value=True)
-            embeddings.append(self.window_embedding(window, mask))
-            mask_idx += self.output_steps
-        x = torch.hstack(embeddings)[:, :cut_off, :]
-        ts = get_timestamps(self.sample_rate, B, input_audio_len, x)
+        B, n_in = audio.shape[0], feats.shape[-1]
+        plan = self.window_plan(n_in, B)
+        feats = torch.nn.functional.pad(feats, (0, plan.pad_frames))
+        per_window = [self.window_embedding(feats[..., w * self.unit_frames:(w + 1) * self.unit_frames], plan.key_masks[w])
+                      for w in range(plan.n_windows)]
+        x = torch.cat(per_window, dim=1)[:, :plan.cut_off]
+        ts = get_timestamps(self.sample_rate, B, n_in, x)
         assert ts.shape[-1] == x.shape[1]
         return x, ts
 
-
-def get_timestamps(sample_rate, B, input_audio_len, x):
-    sec = input_audio_len / sample_rate
-    x_len = x.shape[1]
-    step = sec / x_len * 1000
-    ts = torch.tensor([step * i for i in range(x_len)]).unsqueeze(0)
-    return ts.repeat(B, 1)
+    def get_scene_embeddings(self, audio):
+        return self.get_timestamp_embeddings(audio)[0].mean(dim=1)

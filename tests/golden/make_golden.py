@@ -531,8 +531,51 @@ def gen_hear_scene():
     np.savez_compressed(os.path.join(HERE, "hear_scene.npz"), **fx)
 
 
+def gen_hear_helpers():
+    """The HEAR wrapper's pure helpers as the reference computes them (hear_api/runtime.py:12-35,145-155 imported through the stub
+    recipe; utils.py:1-43 for the run-identity strings): padding mask + cut-off over a sweep of clip lengths for the three window set-ups
+    in use, timestamps, window normalisation."""
+    import importlib
+    import importlib.util
+    RI.install_stubs()
+    if RI.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, RI.REFERENCE_ROOT)
+    ref = importlib.import_module("hear_api.runtime")
+
+    class M:
+        device = torch.device("cpu")
+
+    cases, cuts, lens, trues, trailing = [], [], [], [], []
+    for unit, steps, ps in ((32159, 200, 2), (64319, 200, 4), (16000, 100, 1), (32000, 200, 2)):
+        for n in list(range(1000, 200000, 3777)) + [unit, 2 * unit, unit - 1, unit + 1]:
+            pad = unit - (n % unit)
+            mask, cut = ref.calculate_padding_mask(pad, n + pad, 16000, steps, ps, M(), 2)
+            cases.append((unit, steps, ps, n))
+            cuts.append(cut)
+            lens.append(mask.shape[1])
+            trues.append(int(mask[0].sum()))
+            k = int(mask[0].sum())
+            trailing.append(bool(mask[0, mask.shape[1] - k:].all()) and bool(torch.equal(mask[0], mask[1])))
+    fx = dict(cases=np.array(cases, np.int64), cut=np.array(cuts, np.int64), mask_len=np.array(lens, np.int64),
+              mask_true=np.array(trues, np.int64), mask_is_trailing=np.array(trailing))
+    fx["ts_50000_137"] = ref.get_timestamps(16000, 2, 50000, torch.zeros(2, 137, 8)).numpy()
+    g = torch.Generator().manual_seed(3)
+    win = torch.randn(2, 2, 4000, generator=g) * 3.0 + 0.7
+    fx["norm_in"], fx["norm_out"] = win.numpy(), ref.normalize(win).numpy()
+    spec = importlib.util.spec_from_file_location("ref_root_utils", os.path.join(RI.REFERENCE_ROOT, "utils.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from wavjepa_amd.config import load_config
+    croot = os.path.join(os.path.dirname(os.path.dirname(HERE)), "configs")
+    fx["identity_base"] = np.array(ru.get_identity_from_cfg(load_config(croot, [])))
+    fx["identity_librispeech_bs16"] = np.array(ru.get_identity_from_cfg(load_config(croot, ["masker=LibriSpeech", "trainer.batch_size=16"])))
+    fx["identity_denoise"] = np.array(ru.get_identity_from_cfg_denoise(load_config(croot, [], config_name="denoise")))
+    np.savez_compressed(os.path.join(HERE, "hear_helpers.npz"), **fx)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -552,6 +595,8 @@ if __name__ == "__main__":
         gen_denoiser()
     if "hear_scene" in which:
         gen_hear_scene()
+    if "hear_helpers" in which:
+        gen_hear_helpers()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

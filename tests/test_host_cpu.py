@@ -327,34 +327,54 @@ def test_hear_runtime_padding_arithmetic():
     assert set(sd) == {"encoder.layers.0.linear1.weight", "mask_token"}
 
 
-def test_run_identity_strings_equal_the_reference_output():
+def test_run_identity_strings_equal_the_reference_output(golden_dir):
     """utils.get_identity_from_cfg(_denoise) (reference utils.py:1-43): the checkpoint directory of a configuration.  Expected strings
-    = what the reference's own functions return for these configurations (generated in the build container by importing
-    /root/reference/utils.py on the same config objects)."""
+    = what the reference's own functions returned for these configurations (tests/golden/hear_helpers.npz, make_golden.py)."""
     import utils
     from wavjepa_amd.config import load_config
+    fx = np.load(os.path.join(golden_dir, "hear_helpers.npz"))
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
     cfg = load_config(root, [])
-    want = ("Data=Synthetic_Extractor=wavjepa_InSeconds=2.01_BatchSize=32_NrSamples=8_NrGPUs=1_LR=0.0004_TargetProb=0.25_TargetLen=10_"
-            "ContextProb=0.65_ContextLen=10_MinContextBlock=1_ContextRatio=0.1")
-    assert utils.get_identity_from_cfg(cfg) == want
-    assert utils.checkpoint_dir(cfg, "saved_models_jepa_new_masking", want).endswith(
+    assert utils.get_identity_from_cfg(cfg) == str(fx["identity_base"])
+    assert utils.get_identity_from_cfg(load_config(root, ["masker=LibriSpeech", "trainer.batch_size=16"])) == str(fx["identity_librispeech_bs16"])
+    assert utils.get_identity_from_cfg_denoise(load_config(root, [], config_name="denoise")) == str(fx["identity_denoise"])
+    assert utils.checkpoint_dir(cfg, "saved_models_jepa_new_masking", utils.get_identity_from_cfg(cfg)).endswith(
         "/saved_models_jepa_new_masking/Data=Synthetic/Extractor=wavjepa/InSeconds=2.01/BatchSize=32/NrSamples=8/NrGPUs=1/LR=0.0004/"
         "TargetProb=0.25/TargetLen=10/ContextProb=0.65/ContextLen=10/MinContextBlock=1/ContextRatio=0.1")
-    cfgd = load_config(root, [], config_name="denoise")
-    assert utils.get_identity_from_cfg_denoise(cfgd) == "Data=AudioSet_Extractor=wavjepa_InSeconds=2.01_BatchSize=32_NrSamples=8_NrGPUs=1_LR=0.0001_Alpha=0.0"
+
+
+def test_hear_helpers_equal_the_reference_output(golden_dir):
+    """hear_api.runtime.calculate_padding_mask / get_timestamps / normalize against what the reference's own functions returned
+    (tests/golden/hear_helpers.npz): 228 clip lengths over the window set-ups in use (2.01 s / 200 steps, 4.02 s / 200 steps, ...),
+    including exact multiples of the window and one frame either side."""
+    from hear_api.runtime import calculate_padding_mask, get_timestamps, normalize
+    fx = np.load(os.path.join(golden_dir, "hear_helpers.npz"))
+
+    class M:
+        device = torch.device("cpu")
+
+    assert bool(fx["mask_is_trailing"].all())
+    for (unit, steps, ps, n), cut, mlen, mtrue in zip(fx["cases"].tolist(), fx["cut"].tolist(), fx["mask_len"].tolist(), fx["mask_true"].tolist()):
+        pad = unit - (n % unit)
+        mask, got_cut = calculate_padding_mask(pad, n + pad, 16000, steps, ps, M(), 2)
+        assert got_cut == cut and mask.shape == (2, mlen) and int(mask[0].sum()) == mtrue, (unit, steps, ps, n)
+        assert bool(mask[0, mlen - mtrue:].all()) and torch.equal(mask[0], mask[1])
+    assert np.array_equal(get_timestamps(16000, 2, 50000, torch.zeros(2, 137, 8)).numpy(), fx["ts_50000_137"])
+    assert np.allclose(normalize(torch.from_numpy(fx["norm_in"])).numpy(), fx["norm_out"], rtol=0, atol=1e-6)
 
 
 def test_hear_config_modules_follow_the_hear_contract():
     """hear_configs/*.py (reference hear_configs/WavJEPA.py:11-43, WavJEPA_w2v2.py:11-45): `load_model` builds the runtime without
     weights, window length and steps per window follow the conv spec (2.01 s -> 200 steps; 7-layer spec on 4.02 s -> 200 steps)."""
     import hear_configs.WavJEPA as base
+    import hear_configs.WavJEPA_Nat as nat
     import hear_configs.WavJEPA_w2v2 as w2v2
-    for mod, unit, steps in ((base, int(2.01 * 16000), 200), (w2v2, int(4.02 * 16000), 200)):      # 32159 / 64319 (float product)
-        assert callable(mod.get_scene_embeddings) and callable(mod.get_timestamp_embeddings) and mod.SR == 16000
+    for mod, unit, steps, tokens in ((base, int(2.01 * 16000), 200, 200), (w2v2, int(4.02 * 16000), 200, 200), (nat, int(2.01 * 16000), 200, 400)):
+        assert callable(mod.get_scene_embeddings) and callable(mod.get_timestamp_embeddings) and mod.SR == 16000      # 32159 / 64319 frames
         rt = mod.load_model()
-        assert rt.unit_frames == unit and rt.output_steps == steps and rt.sample_rate == 16000
+        assert rt.unit_frames == unit and rt.output_steps == steps and rt.model.total_patches == tokens and rt.sample_rate == 16000
         assert rt.scene_embedding_size == rt.timestamp_embedding_size == 768
+    assert type(nat.load_model()).__name__ == "RuntimeNatJEPA" and nat.load_model().in_channels == 2
 
 
 def test_mask_plan_takes_group_count_from_the_masks_and_validates_shapes():
