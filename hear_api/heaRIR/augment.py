@@ -1,5 +1,8 @@
-"""reference hear_api/heaRIR/augment.py: wraps a scene iterator and applies one spatial scene per clip."""
-from typing import Optional
+"""Evaluation-time augmentation of the HEAR wrapper: every clip is placed in the next spatial scene of an iterator (source RIR + noise
+RIRs) and, when a noise clip is given, mixed with it at a fixed SNR (reference hear_api/heaRIR/augment.py:8-61: class `Augmenter`,
+`augment(audio, noise=None)`).  Output: [channels, len(audio)] -- the scene's reverberant tail is cut, a mono pass-through gains a
+channel axis."""
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -9,21 +12,21 @@ from .scene_module import generate_scene
 
 class Augmenter:
     def __init__(self, spatial_scene_iter: Optional[SceneIterator], sr: int, snr: Optional[int]):
-        self.spatial_scene_iter = spatial_scene_iter
-        self.sr = sr
-        self.snr = snr
+        self.spatial_scene_iter, self.sr, self.snr = spatial_scene_iter, sr, snr
+
+    def _next_scene(self, device) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        source_rir, noise_rirs, _ = next(self.spatial_scene_iter)
+        return source_rir.to(device), [r.to(device) for r in noise_rirs]
 
     def augment(self, audio: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """audio: normalised 1-D clip (GPU); noise: optional normalised 1-D clip.  Returns [channels, len(audio)]."""
-        n_in = audio.shape[-1]
+        """audio: loudness-normalised 1-D clip; noise: optional loudness-normalised 1-D clip."""
+        keep = audio.shape[-1]
+        out = audio
         if self.spatial_scene_iter:
-            source_rir, noise_rirs, _ = next(self.spatial_scene_iter)
-            source_rir = source_rir.to(audio.device)
-            noise_rirs = [r.to(audio.device) for r in noise_rirs]
-            if source_rir.shape[-1] > n_in:      # a RIR longer than the clip: zero-extend the clip first
-                audio = torch.nn.functional.pad(audio, (0, source_rir.shape[-1] - n_in), value=0, mode="constant")
-            audio = generate_scene(source_rir=source_rir, noise_rirs=[] if noise is None else noise_rirs, source=audio, noise=noise,
-                                   snr=self.snr, sr=self.sr)
-        if audio.ndim == 1:
-            audio = torch.unsqueeze(audio, 0)
-        return audio[:, :n_in]
+            rir, noise_rirs = self._next_scene(audio.device)
+            shortfall = rir.shape[-1] - keep
+            if shortfall > 0:                       # a RIR longer than the clip: the clip is zero-extended to the RIR's length first
+                out = torch.nn.functional.pad(out, (0, shortfall))
+            out = generate_scene(source_rir=rir, noise_rirs=noise_rirs if noise is not None else [], source=out, noise=noise,
+                                 snr=self.snr, sr=self.sr)
+        return (out if out.ndim > 1 else out[None])[:, :keep]
