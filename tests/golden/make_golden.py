@@ -562,6 +562,20 @@ def gen_hear_helpers():
     g = torch.Generator().manual_seed(3)
     win = torch.randn(2, 2, 4000, generator=g) * 3.0 + 0.7
     fx["norm_in"], fx["norm_out"] = win.numpy(), ref.normalize(win).numpy()
+    # feature_helper.FeatureExtractor._wav2feature (CPU part of the reference's pre-processing): loudness + channel fixing
+    fh = importlib.import_module("hear_api.feature_helper")
+    clips = {1: torch.randn(2, 1, 3000, generator=g) * 0.2, 2: torch.randn(2, 2, 3000, generator=g) * 0.05, 4: torch.randn(2, 4, 3000, generator=g)}
+    for c_in, batch in clips.items():
+        fx[f"feat_in_{c_in}"] = batch.numpy()
+        for c_out in (1, 2, 4):
+            if (c_in, c_out) in ((2, 4),):
+                continue                                     # upstream raises for stereo -> 4 channels
+            fx[f"feat_{c_in}_to_{c_out}"] = fh.FeatureExtractor(in_channels=c_out)._wav2feature(batch).numpy()
+    flat = torch.randn(2, 3000, generator=g) * 0.3           # [B, n]: 1-D clips
+    fx["feat_in_flat"], fx["feat_flat_to_2"] = flat.numpy(), fh.FeatureExtractor(in_channels=2)._wav2feature(flat).numpy()
+    tposed = torch.randn(1, 3000, 2, generator=g) * 0.1      # [n, channels] clips are transposed when n > 100
+    fx["feat_in_tposed"], fx["feat_tposed_to_2"] = tposed.numpy(), fh.FeatureExtractor(in_channels=2)._wav2feature(tposed).numpy()
+    fx["feat_silent_to_1"] = fh.FeatureExtractor(in_channels=1)._wav2feature(torch.zeros(1, 1, 500)).numpy()
     spec = importlib.util.spec_from_file_location("ref_root_utils", os.path.join(RI.REFERENCE_ROOT, "utils.py"))
     ru = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ru)

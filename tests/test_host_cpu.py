@@ -361,6 +361,17 @@ def test_hear_helpers_equal_the_reference_output(golden_dir):
         assert bool(mask[0, mlen - mtrue:].all()) and torch.equal(mask[0], mask[1])
     assert np.array_equal(get_timestamps(16000, 2, 50000, torch.zeros(2, 137, 8)).numpy(), fx["ts_50000_137"])
     assert np.allclose(normalize(torch.from_numpy(fx["norm_in"])).numpy(), fx["norm_out"], rtol=0, atol=1e-6)
+    # feature_helper.FeatureExtractor._wav2feature (reference feature_helper.py:27-84): -14 dBFS per clip, channel count fixed
+    from hear_api.feature_helper import FeatureExtractor
+    cases = [k for k in fx.files if k.startswith("feat_") and "_to_" in k]
+    assert len(cases) == 11
+    for k in cases:
+        src, dst = k[5:].split("_to_")
+        x = torch.zeros(1, 1, 500) if src == "silent" else torch.from_numpy(fx["feat_in_" + src])
+        out = FeatureExtractor(in_channels=int(dst))._wav2feature(x).numpy()
+        assert out.shape == fx[k].shape and np.allclose(out, fx[k], rtol=1e-6, atol=1e-7), k
+    with pytest.raises(Exception):
+        FeatureExtractor(in_channels=4)._wav2feature(torch.from_numpy(fx["feat_in_2"]))       # stereo -> 4 channels: undefined upstream too
 
 
 def test_hear_config_modules_follow_the_hear_contract():
