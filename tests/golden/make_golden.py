@@ -588,6 +588,38 @@ def gen_hear_helpers():
     np.savez_compressed(os.path.join(HERE, "hear_helpers.npz"), **fx)
 
 
+def gen_hear_runtime():
+    """The reference's own RuntimeJEPA (hear_api/runtime.py:38-145) on the CPU in fp32: base model, weights = synth_state_dict(seed 23) as
+    the GPU test builds them, two clips of 50 000 samples -> 2 windows.  Only change for the run: FeatureExtractor.forward's `.cuda()`
+    (feature_helper.py:86-88) is skipped -- the container has no GPU.  Stored: embeddings on a (step, channel) sub-grid, timestamps,
+    scene embeddings."""
+    import importlib
+    RI.install_stubs()
+    if RI.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, RI.REFERENCE_ROOT)
+    ref_rt = importlib.import_module("hear_api.runtime")
+    fh = importlib.import_module("hear_api.feature_helper")
+    from wavjepa.extractors import ConvFeatureExtractor
+    fh.FeatureExtractor.forward = lambda self, x: self._wav2feature(x)
+    ext = ConvFeatureExtractor(conv_layers_spec=[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)], in_channels=1)
+    rt = ref_rt.RuntimeJEPA(in_channels=1, weights={"state_dict": {}}, is_spectrogram=False, process_seconds=2.01, extractor=ext,
+                            model_size="base", sr=16000)
+    own = rt.model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in own.items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=23).items()}
+    for k in ("pos_encoding_encoder", "pos_encoding_decoder"):
+        sd[k] = own[k].detach().clone()
+    rt.model.load_state_dict(sd)
+    rt.model.float()
+    wave = torch.from_numpy(synth.synth_audio(2, 1, 50000, seed=29 + 50000)).float()[:, 0]
+    with torch.no_grad():
+        emb, ts = rt.get_timestamp_embeddings(wave)
+        scene = rt.get_scene_embeddings(wave)
+    fx = dict(n_samples=np.int64(50000), seed_weights=np.int64(23), seed_audio=np.int64(29 + 50000), emb_shape=np.array(emb.shape, np.int64),
+              emb_sub=emb[:, ::7, ::5].numpy(), emb_norm=np.float64(emb.double().norm()), ts=ts.numpy(), scene=scene.numpy())
+    np.savez_compressed(os.path.join(HERE, "hear_runtime.npz"), **fx)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
@@ -611,6 +643,8 @@ if __name__ == "__main__":
         gen_hear_scene()
     if "hear_helpers" in which:
         gen_hear_helpers()
+    if "hear_runtime" in which:       # ~1 min of CPU (base model, 2 windows x 2 clips): not part of the default list
+        gen_hear_runtime()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

@@ -777,6 +777,14 @@ def test_hear_runtime_timestamp_embeddings_vs_oracle():
         assert rel(emb, ref) < 2e-2, (n_samples, rel(emb, ref))
         scene = rt.get_scene_embeddings(wave)
         assert scene.shape == (2, 768) and rel(scene, ref.mean(1)) < 2e-2
+        if n_samples == 50000:
+            # the same clips and weights through the REFERENCE's RuntimeJEPA (CPU fp32; tests/golden/hear_runtime.npz, make_golden.py)
+            fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hear_runtime.npz"))
+            assert int(fx["n_samples"]) == n_samples and tuple(fx["emb_shape"]) == tuple(emb.shape)
+            assert np.allclose(ts.cpu().numpy(), fx["ts"], atol=1e-3)
+            assert rel(emb[:, ::7, ::5], torch.from_numpy(fx["emb_sub"])) < 2e-2, rel(emb[:, ::7, ::5], torch.from_numpy(fx["emb_sub"]))
+            assert rel(scene, torch.from_numpy(fx["scene"])) < 2e-2
+            assert rel(ref[:, ::7, ::5], torch.from_numpy(fx["emb_sub"])) < 1e-4        # the oracle restates the reference
 
 
 def test_hear_nat_runtime_timestamp_embeddings_vs_oracle():
