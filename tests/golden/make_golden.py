@@ -588,6 +588,30 @@ def gen_hear_helpers():
     np.savez_compressed(os.path.join(HERE, "hear_helpers.npz"), **fx)
 
 
+def gen_dataset_functions():
+    """data_modules/dataset_functions.py of the reference on seeded clips (pre_process, pre_process_noise, instance_normalize,
+    pad_or_truncate(_batch)): inputs are regenerated from the seed in the test, outputs stored."""
+    import importlib.util
+    RI.install_stubs()
+    spec = importlib.util.spec_from_file_location("ref_dataset_functions", os.path.join(RI.REFERENCE_ROOT, "data_modules", "dataset_functions.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    g = torch.Generator().manual_seed(77)
+    fx = {}
+    for n in (1000, 160000, 170001):
+        w = torch.randn(n, generator=g) * 0.3
+        fx[f"pre_process_{n}"] = R.pre_process(w, 16000).numpy()[:, ::97]
+        fx[f"pre_process_noise_{n}"] = R.pre_process_noise(w).numpy()[..., ::97]
+        fx[f"instance_normalize_{n}"] = R.instance_normalize(w).numpy()[..., ::97]
+        fx[f"shape_pre_process_{n}"] = np.array(R.pre_process(w, 16000).shape, np.int64)
+        fx[f"shape_pre_process_noise_{n}"] = np.array(R.pre_process_noise(w).shape, np.int64)
+    f2 = torch.randn(2, 50, generator=g)
+    for tl in (30, 50, 70):
+        fx[f"pad_or_truncate_{tl}"] = R.pad_or_truncate(f2, tl).numpy()
+        fx[f"pad_or_truncate_batch_{tl}"] = R.pad_or_truncate_batch(f2[None], tl).numpy()
+    np.savez_compressed(os.path.join(HERE, "dataset_functions.npz"), **fx)
+
+
 def gen_hear_runtime():
     """The reference's own RuntimeJEPA (hear_api/runtime.py:38-145) on the CPU in fp32: base model, weights = synth_state_dict(seed 23) as
     the GPU test builds them, two clips of 50 000 samples -> 2 windows.  Only change for the run: FeatureExtractor.forward's `.cuda()`
@@ -621,7 +645,7 @@ def gen_hear_runtime():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers", "dataset_functions"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -643,6 +667,8 @@ if __name__ == "__main__":
         gen_hear_scene()
     if "hear_helpers" in which:
         gen_hear_helpers()
+    if "dataset_functions" in which:
+        gen_dataset_functions()
     if "hear_runtime" in which:       # ~1 min of CPU (base model, 2 windows x 2 clips): not part of the default list
         gen_hear_runtime()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
