@@ -612,6 +612,25 @@ def gen_dataset_functions():
     np.savez_compressed(os.path.join(HERE, "dataset_functions.npz"), **fx)
 
 
+SITE_KEYS = ("data_dirs", "data_dir", "rir_dir", "noise_dir", "save_dir", "teacher_ckpt_weights")     # the authors' cluster paths
+
+
+def gen_configs():
+    """The reference's configs/ tree parsed (yaml.safe_load per file), site-specific path values dropped: the schema and every
+    hyper-parameter value a run of the reference would see."""
+    import json
+    import yaml
+    root = os.path.join(RI.REFERENCE_ROOT, "configs")
+    tree = {}
+    for d, _, files in os.walk(root):
+        for f in sorted(files):
+            if f.endswith(".yaml"):
+                doc = yaml.safe_load(open(os.path.join(d, f)))
+                tree[os.path.relpath(os.path.join(d, f), root)] = {k: ("<site path>" if k in SITE_KEYS else v) for k, v in doc.items()}
+    with open(os.path.join(HERE, "configs_ref.json"), "w") as fh:
+        json.dump(tree, fh, indent=1, sort_keys=True)
+
+
 def gen_hear_runtime():
     """The reference's own RuntimeJEPA (hear_api/runtime.py:38-145) on the CPU in fp32: base model, weights = synth_state_dict(seed 23) as
     the GPU test builds them, two clips of 50 000 samples -> 2 windows.  Only change for the run: FeatureExtractor.forward's `.cuda()`
@@ -645,7 +664,7 @@ def gen_hear_runtime():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers", "dataset_functions"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers", "dataset_functions", "configs"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -669,6 +688,8 @@ if __name__ == "__main__":
         gen_hear_helpers()
     if "dataset_functions" in which:
         gen_dataset_functions()
+    if "configs" in which:
+        gen_configs()
     if "hear_runtime" in which:       # ~1 min of CPU (base model, 2 windows x 2 clips): not part of the default list
         gen_hear_runtime()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list

@@ -374,6 +374,34 @@ def test_hear_helpers_equal_the_reference_output(golden_dir):
         FeatureExtractor(in_channels=4)._wav2feature(torch.from_numpy(fx["feat_in_2"]))       # stereo -> 4 channels: undefined upstream too
 
 
+def test_config_tree_carries_the_reference_schema_and_values(golden_dir):
+    """configs/ against the reference's tree (tests/golden/configs_ref.json = its YAML files parsed, cluster paths dropped): every file
+    and key exists here with the same value.  Deliberate differences, each listed: the default data group is the synthetic source
+    (no corpus in the image), one GPU and no torch.compile by default, `trainer: denoise` in the reference's denoise.yaml names a file
+    that does not exist there (`denoise_audioset` here), and `lr: 1e-4` is a YAML string upstream (a float here)."""
+    import json
+    import yaml
+    ref = json.load(open(os.path.join(golden_dir, "configs_ref.json")))
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
+    allowed = {("base.yaml", "defaults"), ("denoise.yaml", "defaults"), ("trainer/default_trainer.yaml", "num_gpus"),
+               ("trainer/default_trainer.yaml", "compile_modules"), ("trainer/denoise_audioset.yaml", "num_gpus"),
+               ("trainer/denoise_librispeech.yaml", "num_gpus"), ("optimizer/adamW_denoise.yaml", "lr")}
+    seen = set()
+    for rel_path, doc in ref.items():
+        mine = yaml.safe_load(open(os.path.join(root, rel_path)))
+        for k, v in doc.items():
+            assert k in mine, (rel_path, k)
+            if v == "<site path>":
+                assert isinstance(mine[k], str) and mine[k]
+            elif (rel_path, k) in allowed:
+                seen.add((rel_path, k))
+                if k == "lr":
+                    assert float(mine[k]) == float(v)
+            else:
+                assert mine[k] == v, (rel_path, k, mine[k], v)
+    assert seen == allowed
+
+
 def test_hear_config_modules_follow_the_hear_contract():
     """hear_configs/*.py (reference hear_configs/WavJEPA.py:11-43, WavJEPA_w2v2.py:11-45): `load_model` builds the runtime without
     weights, window length and steps per window follow the conv spec (2.01 s -> 200 steps; 7-layer spec on 4.02 s -> 200 steps)."""
