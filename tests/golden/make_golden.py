@@ -26,6 +26,7 @@ Fixtures written:
                       grad norm, lr, EMA decay, final parameter checksums and slices (the north-star trajectory).
 """
 import os
+import inspect
 import sys
 import time
 
@@ -631,6 +632,45 @@ def gen_configs():
         json.dump(tree, fh, indent=1, sort_keys=True)
 
 
+def gen_signatures():
+    """Constructor / call signatures of the reference's public classes on and around the path (parameter names in order + defaults that
+    JSON can hold): the drop-in surface a caller of the reference relies on."""
+    import importlib
+    import json
+    RI.install_stubs()
+    if RI.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, RI.REFERENCE_ROOT)
+    targets = {
+        "JEPA.__init__": ("wavjepa.jepa", "JEPA", "__init__"), "JEPA.forward": ("wavjepa.jepa", "JEPA", "forward"),
+        "JEPA.get_audio_representation": ("wavjepa.jepa", "JEPA", "get_audio_representation"),
+        "JEPA.training_step": ("wavjepa.jepa", "JEPA", "training_step"),
+        "Denoiser.__init__": ("wavjepa.denoiser", "Denoiser", "__init__"), "Denoiser.forward": ("wavjepa.denoiser", "Denoiser", "forward"),
+        "ConvFeatureExtractor.__init__": ("wavjepa.extractors.audio_feature_extractor", "ConvFeatureExtractor", "__init__"),
+        "ConvChannelFeatureExtractor.__init__": ("wavjepa.extractors.audio_channel_feature_extractor", "ConvChannelFeatureExtractor", "__init__"),
+        "TimeInverseBlockMasker.__init__": ("wavjepa.masking", "TimeInverseBlockMasker", "__init__"),
+        "TimeInverseBlockMasker.__call__": ("wavjepa.masking", "TimeInverseBlockMasker", "__call__"),
+        "SpeechMasker.__init__": ("wavjepa.masking", "SpeechMasker", "__init__"),
+        "RuntimeJEPA.__init__": ("hear_api.runtime", "RuntimeJEPA", "__init__"),
+        "RuntimeNatJEPA.__init__": ("hear_api.runtime_natjepa", "RuntimeNatJEPA", "__init__"),
+        "WebAudioDataModule.__init__": ("data_modules.WebAudioDataModule", "WebAudioDataModule", "__init__"),
+        "WebAudioDataModuleDenoiser.__init__": ("data_modules.WebAudioDataModuleDenoiser", "WebAudioDataModuleDenoiser", "__init__"),
+    }
+    out = {}
+    for name, (mod, cls, fn) in targets.items():
+        f = getattr(getattr(importlib.import_module(mod), cls), fn)
+        params = []
+        for p in inspect.signature(f).parameters.values():
+            d = p.default
+            if d is inspect.Parameter.empty:
+                d = "<required>"
+            elif not isinstance(d, (int, float, str, bool, type(None), list, tuple)):
+                d = "<object>"
+            params.append([p.name, str(p.kind).split(".")[-1], list(d) if isinstance(d, tuple) else d])
+        out[name] = params
+    with open(os.path.join(HERE, "signatures_ref.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 def gen_hear_runtime():
     """The reference's own RuntimeJEPA (hear_api/runtime.py:38-145) on the CPU in fp32: base model, weights = synth_state_dict(seed 23) as
     the GPU test builds them, two clips of 50 000 samples -> 2 windows.  Only change for the run: FeatureExtractor.forward's `.cuda()`
@@ -664,7 +704,7 @@ def gen_hear_runtime():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers", "dataset_functions", "configs"]
+    which = sys.argv[1:] or ["masks", "tiny", "traj", "crops", "misc", "base", "channel", "scene", "denoiser", "hear_scene", "hear_helpers", "dataset_functions", "configs", "signatures"]
     masks = gen_masks() if "masks" in which else dict(np.load(os.path.join(HERE, "masks.npz")))
     if "tiny" in which:
         gen_tiny(masks)
@@ -690,6 +730,8 @@ if __name__ == "__main__":
         gen_dataset_functions()
     if "configs" in which:
         gen_configs()
+    if "signatures" in which:
+        gen_signatures()
     if "hear_runtime" in which:       # ~1 min of CPU (base model, 2 windows x 2 clips): not part of the default list
         gen_hear_runtime()
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list

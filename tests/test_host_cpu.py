@@ -374,6 +374,39 @@ def test_hear_helpers_equal_the_reference_output(golden_dir):
         FeatureExtractor(in_channels=4)._wav2feature(torch.from_numpy(fx["feat_in_2"]))       # stereo -> 4 channels: undefined upstream too
 
 
+def test_public_signatures_match_the_reference(golden_dir):
+    """Drop-in surface: every parameter (name, default) of the reference's constructors / entry points on the path exists here
+    (tests/golden/signatures_ref.json = inspect.signature of the reference's classes).  Additions, all keyword-only in use:
+    JEPA(warmup_steps=), maskers(channel_major=), data modules(seed=, rank=, world_size=)."""
+    import importlib
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(golden_dir, "signatures_ref.json")))
+    where = {"JEPA": "wavjepa_amd.jepa", "Denoiser": "wavjepa_amd.denoiser", "ConvFeatureExtractor": "wavjepa_amd.extractors",
+             "ConvChannelFeatureExtractor": "wavjepa_amd.extractors", "TimeInverseBlockMasker": "wavjepa_amd.masking",
+             "SpeechMasker": "wavjepa_amd.masking", "RuntimeJEPA": "hear_api.runtime", "RuntimeNatJEPA": "hear_api.runtime_natjepa",
+             "WebAudioDataModule": "wavjepa_amd.data_modules", "WebAudioDataModuleDenoiser": "wavjepa_amd.data_modules"}
+    allowed_extra = {"warmup_steps", "channel_major", "seed", "rank", "world_size"}
+    assert len(ref) == 15
+    for name, params in ref.items():
+        cls, fn = name.split(".")
+        f = getattr(getattr(importlib.import_module(where[cls]), cls), fn)
+        mine = {p.name: p.default for p in inspect.signature(f).parameters.values()}
+        names = [p[0] for p in params]
+        for pname, kind, default in params:
+            if kind in ("VAR_POSITIONAL", "VAR_KEYWORD"):
+                continue
+            assert pname in mine, (name, pname)
+            d = mine[pname]
+            if default == "<required>":
+                assert d is inspect.Parameter.empty, (name, pname)
+            elif default != "<object>":
+                assert (list(d) if isinstance(d, tuple) else d) == default, (name, pname, d, default)
+        assert {k for k in mine if k not in names} <= allowed_extra, (name, set(mine) - set(names))
+        positional = [p for p in names if p in mine]
+        assert [k for k in mine if k in positional] == positional, (name, "parameter order")
+
+
 def test_config_tree_carries_the_reference_schema_and_values(golden_dir):
     """configs/ against the reference's tree (tests/golden/configs_ref.json = its YAML files parsed, cluster paths dropped): every file
     and key exists here with the same value.  Deliberate differences, each listed: the default data group is the synthetic source
