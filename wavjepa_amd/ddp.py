@@ -10,7 +10,6 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
-import torch
 import torch.distributed as dist
 
 from .params import FlatParams
