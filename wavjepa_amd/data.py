@@ -9,7 +9,6 @@ from typing import List, Tuple
 
 import torch
 
-from .engine import MaskPlan, make_mask_plan
 
 
 class SyntheticAudioSource:

@@ -12,7 +12,6 @@ directories are mixed with `mixing_weights` (webdataset's RandomMix: a source is
 batch).  Workers are the torch DataLoader's processes, as upstream.
 """
 import glob
-import io
 import os
 import random
 import re

@@ -12,7 +12,6 @@ P_{l-1} = stride_l * P_l; a strided conv is then ONE GEMM with lda = stride*C an
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 

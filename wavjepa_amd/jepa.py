@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import copy
 import math
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, Optional
 
 import numpy as np
 import torch

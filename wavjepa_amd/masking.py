@@ -3,7 +3,6 @@
 (reference wavjepa/masking.py:7-128 TimeInverseBlockMasker, :131-207 SpeechMasker)."""
 from __future__ import annotations
 
-import numpy as np
 import torch
 from torch import nn
 
