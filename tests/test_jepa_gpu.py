@@ -22,6 +22,13 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
@@ -410,7 +417,7 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16",
            "--dense-steps", "1", "--no-cpu-baseline", "--no-profile"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -428,7 +435,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--clips-per-gpu", "16",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--clips-per-gpu", "16",
            "--dense-steps", "0", "--no-cpu-baseline", "--no-profile"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"))
     assert r.returncode == 0, r.stderr[-2000:]
