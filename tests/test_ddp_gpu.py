@@ -135,18 +135,18 @@ def test_two_ranks_on_one_gpu_average_gradients_and_stay_identical(golden_dir):
 def test_train_py_two_ranks_share_the_gpu_over_gloo(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 train.py trainer.num_gpus=2 ...` end to end (reference train.py:174-179,
     strategy="ddp"): per-rank synthetic sources, Trainer.fit with the bucketed averages, rank 0 alone logs and writes checkpoints."""
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "train.py"), "trainer.num_gpus=2", "trainer.steps=4", "trainer.batch_size=2",
            "data.samples_per_audio=2", "trainer.log_every_n_steps=2", f"save_dir={tmp_path / 'runs'}"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"))
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    steps = [ln for ln in r.stdout.splitlines() if ln.startswith("step ")]
-    assert [ln.split()[1] for ln in steps] == ["2", "4"], r.stdout[-1500:]                         # one logger (rank 0), not two
+    from tests import launch
+    rc, out, err = launch.run(cmd, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"), timeout=300)
+    assert rc == 0, (out[-1500:], err[-4000:])
+    steps = [ln for ln in out.splitlines() if ln.startswith("step ")]
+    assert [ln.split()[1] for ln in steps] == ["2", "4"], out[-1500:]                              # one logger (rank 0), not two
     assert all(np.isfinite(float(ln.split("loss")[1].split()[0])) for ln in steps)
-    assert "Effective Batch Size is: 8" in r.stdout                                                # 2 sources x 2 crops x 2 ranks
+    assert "Effective Batch Size is: 8" in out                                                     # 2 sources x 2 crops x 2 ranks
     ckpts = list((tmp_path / "runs").rglob("last.ckpt"))
     assert len(ckpts) == 1 and "NrGPUs=2" in str(ckpts[0])
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests import launch
 import synth
 from oracle import jepa_oracle as J
 
@@ -21,12 +22,6 @@ BASE = dict(conv_spec=list(J.WAVJEPA_CONV_SPEC), d_enc=768, h_enc=12, l_enc=12, 
 def dev():
     return torch.device("cuda:0")
 
-
-def _free_port():
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def rel(a, b):
@@ -413,15 +408,14 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
     """The driver's N > 1 launch path (python -m torch.distributed.run ... bench.py) with a 1-rank process group: RCCL
     init, parameter broadcast, bucketed all-reduce hooks and the replica checksum all execute on the single GPU box."""
     import json
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16",
+           "--master-port", str(launch.free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "16",
            "--dense-steps", "1", "--no-cpu-baseline", "--no-profile"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rc, out, err = launch.run(cmd, cwd=root, timeout=300)
+    assert rc == 0, err[-4000:]
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["replicas_equal"] is True and line["value"] > 0 and line["dense_ms_per_step"] > 0
     assert line["config"]["global_batch"] == 16
 
@@ -431,15 +425,14 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     gloo (WJ_DIST_BACKEND, a development switch of init_distributed); everything else -- per-rank sources, broadcast, bucketed
     averages from the backward's hooks, max-over-ranks timing, whole-job value, the replica checksum -- is the driver's path."""
     import json
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--clips-per-gpu", "16",
+           "--master-port", str(launch.free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--clips-per-gpu", "16",
            "--dense-steps", "0", "--no-cpu-baseline", "--no-profile"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    rc, out, err = launch.run(cmd, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"), timeout=300)
+    assert rc == 0, err[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "rank 0 alone prints the JSON line"
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["replicas_equal"] is True and line["scaling"] == "weak"
