@@ -16,7 +16,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
@@ -74,7 +74,7 @@ def test_bucketed_allreduce_world2():
 def _grad_worker(rank, world, port, q):
     """Each rank: its OWN micro-batch, gradients of its own loss (normalised by its LOCAL target count, reference
     jepa.py:359-362) written into the flat gradient buffer at the slots the engine uses, then the bucketed all-reduce."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
@@ -151,7 +151,7 @@ def test_ddp_gradient_equals_mean_of_per_rank_gradients_world2():
 def _denoiser_worker(rank, world, port, q):
     """Denoiser stage under data parallelism: a module without an EMA copy (empty teacher buffer) broadcasts its parameters and averages
     its whole flat gradient buffer in one collective (`FlatGradAllReducer.reduce_all`; the stage has no backward section hooks)."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys

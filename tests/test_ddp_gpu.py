@@ -21,7 +21,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, golden_dir, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys

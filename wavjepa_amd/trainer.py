@@ -33,6 +33,10 @@ def init_distributed() -> tuple:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
+            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+                # gloo binds to the interface the HOSTNAME resolves to; container hostnames often do not resolve (or do after a resolver
+                # time-out): a one-node run stays on the loopback interface
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
