@@ -136,4 +136,7 @@ class Trainer:
                 self.save_checkpoint(model, runner, os.path.join(self.root, f"step={gs}.ckpt"))
         if self.root:
             self.save_checkpoint(model, runner, os.path.join(self.root, "last.ckpt"))
+        if self.rank == 0 and self.log_every_n_steps:
+            print(f"done: {model.global_step} steps, peak HBM {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB allocated, "
+                  f"{torch.cuda.max_memory_reserved(dev) / 2**30:.1f} GiB reserved", flush=True)
         return runner
