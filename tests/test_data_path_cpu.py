@@ -104,6 +104,70 @@ def test_flac_detects_corruption():
         A.decode_audio(good, "mp3")
 
 
+def test_flac_decoder_on_the_rfc9639_example_streams():
+    """Independent vectors (tests/golden/make_flac_rfc9639.py): the three complete streams RFC 9639 prints, written by the reference
+    encoder, each carrying that encoder's CRC-8 / CRC-16 / MD5 -- decoded here with the MD5 check on, and compared sample by sample."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flac_rfc9639.npz"))
+    expect = {"ex1": (44100, 2, 16), "ex2": (44100, 2, 16), "ex3": (32000, 1, 8)}
+    for name, (rate, ch, bps) in expect.items():
+        data = z[name + "_bytes"].tobytes()
+        pcm, si = A.decode_flac_pcm(data, verify_md5=True)
+        assert (si.sample_rate, si.channels, si.bits_per_sample) == (rate, ch, bps)
+        assert any(si.md5) and np.array_equal(pcm.T, z[name + "_pcm"]), name
+        wav, sr = A.decode_flac(data, verify_md5=True)
+        assert sr == rate and wav.shape == (ch, z[name + "_pcm"].shape[1]) and float(wav.abs().max()) < 1.0
+        # the counting pass (streams of unknown length) agrees with STREAMINFO
+        assert A._lib().wj_flac_decode(data, len(data), None, 0) == si.total_samples
+    # unknown total length (the field zeroed: the MD5 still covers the samples) takes the counting pass
+    data = bytearray(z["ex2_bytes"].tobytes())
+    data[8 + 13] &= 0xf0
+    data[8 + 14:8 + 18] = bytes(4)
+    pcm, si = A.decode_flac_pcm(bytes(data), verify_md5=True)
+    assert si.total_samples == 0 and np.array_equal(pcm.T, z["ex2_pcm"])
+    # an absurd STREAMINFO sample count is refused before any allocation
+    data = bytearray(z["ex2_bytes"].tobytes())
+    data[8 + 13] |= 0x0f
+    with pytest.raises(A.AudioDecodeError, match="exceed"):
+        A.decode_flac_pcm(bytes(data))
+
+
+def test_flac_decoder_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """csrc/flac_decode.cpp parses untrusted bitstreams: built with -fsanitize=address,undefined (no recovery) and driven by
+    tests/flac_fuzz_main.cpp over the RFC streams and encoder outputs of every subframe kind, each through thousands of random
+    mutations.  Any out-of-bounds access, signed overflow or bad shift aborts the driver."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("g++ not available")
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(os.path.dirname(here), "wavjepa_amd", "csrc", "flac_decode.cpp")
+    exe = str(tmp_path / "flac_fuzz")
+    r = subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, src,
+                        os.path.join(here, "flac_fuzz_main.cpp")], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and ("cannot find" in r.stderr or "unrecognized" in r.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr
+    z = np.load(os.path.join(here, "golden", "flac_rfc9639.npz"))
+    files = []
+    for name in ("ex1", "ex2", "ex3"):
+        f = tmp_path / f"{name}.flac"
+        f.write_bytes(z[name + "_bytes"].tobytes())
+        files.append(str(f))
+    pcm2 = tone_pcm(3000, 2, 16, seed=3)
+    corpus = [E.encode(pcm2, 16000, 16, blocksize=576, stereo="mid_side", subframes=[SPECS[3], SPECS[8]]),
+              E.encode(tone_pcm(2500, 1, 24, seed=4), 48000, 24, blocksize=1024, subframes=SPECS[5]),
+              E.encode(tone_pcm(2000, 2, 12, seed=5), 8000, 12, blocksize=256, stereo="left_side", subframes=[SPECS[7], SPECS[9]])]
+    for i, data in enumerate(corpus):
+        f = tmp_path / f"enc{i}.flac"
+        f.write_bytes(data)
+        files.append(str(f))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([exe, "2500", "12345"] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "mutations decoded" in r.stdout
+
+
 def test_dataset_functions_match_the_reference():
     """Known answers + the reference's own data_modules/dataset_functions.py outputs (fixture)."""
     from wavjepa_amd.data_modules import dataset_functions as F

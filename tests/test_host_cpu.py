@@ -537,5 +537,18 @@ def test_compiled_kernels_have_no_mfma_result_read_across_a_branch(tmp_path):
         return name, r.returncode, r.stdout[-1500:]
 
     with ThreadPoolExecutor(max_workers=4) as ex:
-        for name, rc, out in ex.map(scan, ["attention", "gemm", "norm", "conv0", "fp8"]):
+        for name, rc, out in ex.map(scan, ["attention", "gemm", "gemm_persist", "norm", "conv0", "fp8"]):
             assert rc == 0, (name, out)
+
+
+def test_persistent_gemm_assembly_keeps_the_pulled_tile_index_register_untouched():
+    """csrc/gemm_persist.hip pulls its next tile with a returning atomic from inline asm (hipcc must not see the result register, or
+    it waits for it with vmcnt(0) and drains the LDS-DMA ring).  tools/asm_checks.py proves on the gfx950 assembly of THIS build that
+    nothing reads, copies or spills that register between the atomic and the ds_write that consumes it, and that no kernel of the file
+    touches scratch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_checks.py")], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "pulls checked" in r.stdout

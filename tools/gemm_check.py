@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Race screen + A/B for a GEMM schedule variant (run on the GPU box): every listed shape is computed with the reference
-variant and with the variant under test, many times, on fresh random operands; outputs must agree BIT for bit (all schedules add
-the k index in the same order) on every repetition.  Then interleaved timing rounds of both variants in one process."""
+variant and with the variant under test, many times, on fresh random operands.  Variants 0-3 must agree BIT for bit (they add the k
+index in the same order and the bias last); variant 4 starts its accumulators FROM the bias (fp32 (b + sum) instead of (sum + b)), so
+against it a rare last-place difference of the bf16 output is allowed: <= 2 % of the elements, each within 2 bf16 ulps (+ 1e-4
+absolute where sum and bias cancel; + 4e-3 for the GELU outputs), and its own repetitions must be bit-identical to each other.  A race shows as a large difference
+in a few tiles.  Then interleaved timing rounds of both variants in one process."""
 import os
 import sys
 
@@ -18,6 +21,9 @@ SHAPES = [  # M, N, K, epilogue
     (9907, 3072, 768, ops.EPI_BIAS_GELU2), (86317, 1536, 384, ops.EPI_BIAS_GELU2), (86317, 1152, 384, ops.EPI_BF16),
     (86317, 384, 1536, ops.EPI_BF16), (86317, 384, 384, ops.EPI_BF16), (8192, 8192, 8192, ops.EPI_BF16),
     (300, 256, 128, ops.EPI_BF16), (257, 512, 256, ops.EPI_BF16), (1000, 264, 384, ops.EPI_BF16),
+    # >= 256 output tiles with ragged edges (the persistent variant's pull / edge paths), short K, conv epilogue
+    (65537, 264, 128, ops.EPI_BF16), (33000, 520, 256, ops.EPI_BIAS_GELU2), (70001, 384, 1536, ops.EPI_BF16),
+    (102912, 512, 1536, ops.EPI_CONV_GELU), (51456, 512, 1024, ops.EPI_CONV_GELU),
 ]
 ref_v, new_v = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 3
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
@@ -34,9 +40,13 @@ for (M, N, K, epi) in SHAPES:
     bias = torch.randn(N, device=dev)
     kw["bias"] = bias
     C2a = C2b = None
-    if epi == ops.EPI_BIAS_GELU2:
+    if epi == ops.EPI_CONV_GELU:
+        kw.pop("bias")
+        kw.update(seg_rows=402, seg_valid=400)
+    if epi in (ops.EPI_BIAS_GELU2, ops.EPI_CONV_GELU):
         C2a, C2b = torch.empty(M, N, device=dev, dtype=bf), torch.empty(M, N, device=dev, dtype=bf)
     worst = 0
+    fracs = []
     for r in range(reps):
         A = torch.randn(M, K, device=dev).to(bf)
         W = (torch.randn(N, K, device=dev) * 0.05).to(bf)
@@ -45,7 +55,23 @@ for (M, N, K, epi) in SHAPES:
         run(ref_v, A, W, Ca, dict(kw, **({"C2": C2a} if C2a is not None else {})))
         run(new_v, A, W, Cb, dict(kw, **({"C2": C2b} if C2b is not None else {})))
         torch.cuda.synchronize()
-        same = torch.equal(Ca.view(torch.int16), Cb.view(torch.int16)) and (C2a is None or torch.equal(C2a.view(torch.int16), C2b.view(torch.int16)))
+        pairs = [(Ca, Cb)] + ([(C2a, C2b)] if C2a is not None else [])
+        same = all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in pairs)
+        if not same and 4 in (ref_v, new_v):
+            same = True
+            for x, y in pairs:
+                xf, yf = x.float(), y.float()
+                d = (xf - yf).abs()
+                frac = float((d > 0).float().mean())
+                ok = bool((d <= 0.0157 * torch.maximum(xf.abs(), yf.abs()) + (4e-3 if epi != ops.EPI_BF16 else 1e-4)).all())
+                same = same and ok and frac <= 0.02 and not bool(torch.isnan(yf).any())
+                fracs.append(frac)
+            # the variant under test against itself: bit-identical
+            Cc = torch.full((M, N), float("nan"), device=dev, dtype=bf)
+            C2c = torch.empty_like(C2b) if C2b is not None else None
+            run(new_v, A, W, Cc, dict(kw, **({"C2": C2c} if C2c is not None else {})))
+            torch.cuda.synchronize()
+            same = same and torch.equal(Cb.view(torch.int16), Cc.view(torch.int16)) and (C2c is None or torch.equal(C2b.view(torch.int16), C2c.view(torch.int16)))
         if not same:
             worst += 1
             d = (Ca.float() - Cb.float()).abs()
@@ -77,7 +103,7 @@ for (M, N, K, epi) in SHAPES:
     fl = 2.0 * M * N * K
     ta, tb = sorted(ts[ref_v])[3], sorted(ts[new_v])[3]
     print(f"M={M:6d} N={N:5d} K={K:5d} epi={epi}: variant {ref_v} {ta * 1e3:7.1f} us {fl / ta / 1e9:7.1f} TF | variant {new_v} {tb * 1e3:7.1f} us "
-          f"{fl / tb / 1e9:7.1f} TF | {'OK' if worst == 0 else 'MISMATCH x%d' % worst}")
+          f"{fl / tb / 1e9:7.1f} TF | {'OK' if worst == 0 else 'MISMATCH x%d' % worst}" + (f" (last-place differences: {max(fracs) * 100:.3f} % of the elements)" if fracs else ""))
 ops.gemm_set_variant(-1)
 print("mismatching repetitions:", bad)
 sys.exit(1 if bad else 0)

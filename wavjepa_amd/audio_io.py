@@ -47,12 +47,23 @@ def flac_info(data: bytes) -> FlacStreamInfo:
     return si
 
 
-def decode_flac_pcm(data: bytes, verify_md5: bool = False) -> Tuple[np.ndarray, FlacStreamInfo]:
+MAX_SAMPLES = 1 << 26      # per channel (23 minutes at 48 kHz): what a training clip can reasonably hold; STREAMINFO is untrusted input
+
+
+def decode_flac_pcm(data: bytes, verify_md5: bool = False, max_samples: int = MAX_SAMPLES) -> Tuple[np.ndarray, FlacStreamInfo]:
     """-> (int32 PCM [samples, channels], stream info).  Frame CRCs are always checked; `verify_md5` also checks the decoded samples
-    against the STREAMINFO signature (skipped when the encoder left it zero)."""
+    against the STREAMINFO signature (skipped when the encoder left it zero).  The output is sized from STREAMINFO's sample count
+    only up to `max_samples` (a corrupt 36-bit field must not ask for terabytes); a stream of unknown length is sized by a counting
+    pass of the decoder (a silent clip compresses far below any bytes-based bound)."""
     si = flac_info(data)
-    cap = int(si.total_samples) if si.total_samples else max(1, len(data)) * 8       # unknown length: generous bound
-    pcm = np.empty((cap, si.channels), dtype=np.int32)
+    cap = int(si.total_samples)
+    if cap == 0:
+        cap = int(_lib().wj_flac_decode(data, len(data), None, 0))
+        if cap < 0:
+            raise AudioDecodeError(f"FLAC: {ERRORS.get(cap, cap)}")
+    if cap > max_samples:
+        raise AudioDecodeError(f"FLAC: {cap} samples per channel exceed the limit of {max_samples}")
+    pcm = np.empty((max(cap, 1), si.channels), dtype=np.int32)
     n = _lib().wj_flac_decode(data, len(data), pcm.ctypes.data, cap)
     if n < 0:
         raise AudioDecodeError(f"FLAC: {ERRORS.get(int(n), int(n))}")
@@ -66,8 +77,8 @@ def decode_flac_pcm(data: bytes, verify_md5: bool = False) -> Tuple[np.ndarray, 
     return pcm, si
 
 
-def decode_flac(data: bytes, verify_md5: bool = False) -> Tuple[torch.Tensor, int]:
-    pcm, si = decode_flac_pcm(data, verify_md5)
+def decode_flac(data: bytes, verify_md5: bool = False, max_samples: int = MAX_SAMPLES) -> Tuple[torch.Tensor, int]:
+    pcm, si = decode_flac_pcm(data, verify_md5, max_samples)
     scale = np.float32(1.0 / float(1 << (si.bits_per_sample - 1)))
     wav = np.ascontiguousarray(pcm.T.astype(np.float32) * scale)
     return torch.from_numpy(wav), int(si.sample_rate)

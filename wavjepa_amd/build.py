@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwavjepa_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip"]
+SOURCES = ["gemm.hip", "gemm_persist.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 
@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_internal.h"), os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

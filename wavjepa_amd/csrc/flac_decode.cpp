@@ -10,7 +10,8 @@
 //
 //   int wj_flac_info(const uint8_t* buf, int64_t len, wj_flac_stream_info* out)           0 or a negative error
 //   int64_t wj_flac_decode(const uint8_t* buf, int64_t len, int32_t* pcm, int64_t capacity_frames)
-//        -> number of inter-channel frames written (pcm[frame * channels + ch]) or a negative error
+//        -> number of inter-channel frames written (pcm[frame * channels + ch]) or a negative error; with pcm == NULL nothing is
+//           written and the number of frames the stream decodes to is returned (sizing pass for streams of unknown length)
 #include <stdint.h>
 #include <string.h>
 
@@ -27,6 +28,12 @@ typedef struct {
 namespace {
 
 enum { ERR_FORMAT = -1, ERR_TRUNCATED = -2, ERR_CRC = -3, ERR_UNSUPPORTED = -4, ERR_CAPACITY = -5 };
+
+// Predictor arithmetic wraps (two's complement) instead of overflowing: a valid stream never comes near 64 bits, a corrupt one
+// (caught by its CRC-16 a few lines later) must not be undefined behaviour on the way (found by the sanitizer fuzz test).
+inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+inline int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+inline int64_t wmul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
 
 struct BitReader {
     const uint8_t* p;
@@ -88,19 +95,23 @@ uint8_t crc8(const uint8_t* d, int64_t n) {
     return c;
 }
 
-uint16_t crc16(const uint8_t* d, int64_t n) {
-    static uint16_t table[256];
-    static bool init = false;
-    if (!init) {
+// CRC-16 table (polynomial 0x8005), built at compile time: loader threads call the decoder concurrently without the GIL, and a
+// lazily initialised static table behind an unsynchronised flag was a data race.
+struct Crc16Table {
+    uint16_t v[256];
+    constexpr Crc16Table() : v() {
         for (int i = 0; i < 256; ++i) {
             uint16_t c = (uint16_t)(i << 8);
             for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x8005) : (uint16_t)(c << 1);
-            table[i] = c;
+            v[i] = c;
         }
-        init = true;
     }
+};
+constexpr Crc16Table CRC16_TABLE;
+
+uint16_t crc16(const uint8_t* d, int64_t n) {
     uint16_t c = 0;
-    for (int64_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table[((c >> 8) ^ d[i]) & 0xff]);
+    for (int64_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ CRC16_TABLE.v[((c >> 8) ^ d[i]) & 0xff]);
     return c;
 }
 
@@ -188,10 +199,10 @@ int read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
         for (int i = order; i < blocksize; ++i) {
             switch (order) {
                 case 0: break;
-                case 1: s[i] += s[i - 1]; break;
-                case 2: s[i] += 2 * s[i - 1] - s[i - 2]; break;
-                case 3: s[i] += 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
-                default: s[i] += 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+                case 1: s[i] = wadd(s[i], s[i - 1]); break;
+                case 2: s[i] = wadd(s[i], wsub(wmul(2, s[i - 1]), s[i - 2])); break;
+                case 3: s[i] = wadd(s[i], wadd(wsub(wmul(3, s[i - 1]), wmul(3, s[i - 2])), s[i - 3])); break;
+                default: s[i] = wadd(s[i], wsub(wadd(wsub(wmul(4, s[i - 1]), wmul(6, s[i - 2])), wmul(4, s[i - 3])), s[i - 4])); break;
             }
         }
     } else if (type >= 32) {                            // LPC, order (type & 31) + 1
@@ -208,8 +219,8 @@ int read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
         if (rc) return rc;
         for (int i = order; i < blocksize; ++i) {
             int64_t acc = 0;
-            for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-            s[i] += acc >> shift;
+            for (int j = 0; j < order; ++j) acc = wadd(acc, wmul(coef[j], s[i - 1 - j]));
+            s[i] = wadd(s[i], acc >> shift);
         }
     } else {
         return ERR_UNSUPPORTED;                         // reserved subframe types
@@ -229,7 +240,8 @@ extern "C" int wj_flac_info(const uint8_t* buf, int64_t len, wj_flac_stream_info
 }
 
 extern "C" int64_t wj_flac_decode(const uint8_t* buf, int64_t len, int32_t* pcm, int64_t capacity_frames) {
-    if (!buf || !pcm || len <= 0) return ERR_FORMAT;
+    if (!buf || len <= 0) return ERR_FORMAT;
+    const bool count_only = pcm == nullptr;
     wj_flac_stream_info si;
     int64_t off = 0;
     int rc = parse_streaminfo(buf, len, &si, &off);
@@ -273,7 +285,7 @@ extern "C" int64_t wj_flac_decode(const uint8_t* buf, int64_t len, int32_t* pcm,
         int channels;
         if (ch_code < 8) channels = ch_code + 1; else if (ch_code <= 10) channels = 2; else return ERR_FORMAT;
         if (channels != si.channels) return ERR_UNSUPPORTED;
-        if (written + blocksize > capacity_frames) return ERR_CAPACITY;
+        if (!count_only && written + blocksize > capacity_frames) return ERR_CAPACITY;
         work.resize((size_t)channels * blocksize);
         for (int ch = 0; ch < channels; ++ch) {
             const bool side = (ch_code == 8 && ch == 1) || (ch_code == 9 && ch == 0) || (ch_code == 10 && ch == 1);
@@ -288,20 +300,22 @@ extern "C" int64_t wj_flac_decode(const uint8_t* buf, int64_t len, int32_t* pcm,
         int64_t* c0 = work.data();
         int64_t* c1 = work.data() + blocksize;
         if (ch_code == 8) {
-            for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
+            for (int i = 0; i < blocksize; ++i) c1[i] = wsub(c0[i], c1[i]);
         } else if (ch_code == 9) {
-            for (int i = 0; i < blocksize; ++i) c0[i] = c0[i] + c1[i];
+            for (int i = 0; i < blocksize; ++i) c0[i] = wadd(c0[i], c1[i]);
         } else if (ch_code == 10) {
             for (int i = 0; i < blocksize; ++i) {
                 const int64_t side = c1[i];
                 const int64_t mid = (int64_t)(((uint64_t)c0[i] << 1) | (uint64_t)(side & 1));
-                c0[i] = (mid + side) >> 1;
-                c1[i] = (mid - side) >> 1;
+                c0[i] = wadd(mid, side) >> 1;
+                c1[i] = wsub(mid, side) >> 1;
             }
         }
-        int32_t* dst = pcm + written * channels;
-        for (int i = 0; i < blocksize; ++i)
-            for (int ch = 0; ch < channels; ++ch) dst[(int64_t)i * channels + ch] = (int32_t)work[(size_t)ch * blocksize + i];
+        if (!count_only) {
+            int32_t* dst = pcm + written * channels;
+            for (int i = 0; i < blocksize; ++i)
+                for (int ch = 0; ch < channels; ++ch) dst[(int64_t)i * channels + ch] = (int32_t)work[(size_t)ch * blocksize + i];
+        }
         written += blocksize;
         off += body + 2;
     }

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
+#include "gemm_internal.h"
 
 namespace {
 
@@ -1102,6 +1103,7 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 //   1 = 256x256 tile, plain schedule     : split-K wgrad (long K loop; 850-1000 TFLOP/s)
 //   2 = 256x256 tile, ping-pong schedule : forward / conv shapes with plain epilogues and K >= 512 (+9..17 % over variant 0)
 //   3 = 256x256x64 tile, eight-phase     : row-form operands, K % 128 == 0 (+10..15 % over variant 2 at K = 768, +35 % at 8192^3)
+//   4 = variant 3's loop, persistent     : >= 256 output tiles, forward epilogues (csrc/gemm_persist.hip)
 // WJ_GEMM_VARIANT=0|1|2|3 (or wj_gemm_set_variant) forces one (A/B runs; 1-3 need N % 256 == 0 to avoid wasted columns but
 // stay correct; a variant that cannot run a shape falls back to 0).
 int g_forced_variant = -2;   // -2: not initialised (WJ_GEMM_VARIANT decides), -1: automatic, >= 0: forced
@@ -1110,8 +1112,12 @@ int pick_variant(const wj_gemm_args* a) {
     if (g_forced_variant == -2) { const char* v = getenv("WJ_GEMM_VARIANT"); g_forced_variant = v ? atoi(v) : -1; }
     const int forced = g_forced_variant;
     const bool ep_ok = !a->a_trans && !a->b_trans && a->K % 128 == 0 && a->split_k <= 1;   // eight-phase schedule (variant 3)
+    if (forced == 4) return wj_gemm_persist_eligible(a) ? 4 : (ep_ok ? 3 : 0);
     if (forced == 3) return ep_ok ? 3 : 0;
     if (forced >= 0 && forced <= 2) return forced;
+    // persistent eight-phase (csrc/gemm_persist.hip): the same K loop without the per-tile prologue / LDS-staged epilogue / dispatch gap
+    // (its edge tiles are shifted inwards: a last tile column narrower than half a tile is mostly duplicate work)
+    if (ep_ok && (a->N % 256 == 0 || a->N % 256 >= 128) && wj_gemm_persist_eligible(a)) return 4;
     // eight-phase (64-deep tiles, full-line fetches): every row-form shape whose N fills 256-wide tiles, and N = 384 with a long
     // K loop (the half-empty second tile still beats the 128-wide variant there); measured with tools/gemm_check.py
     if (ep_ok && (a->N % 256 == 0 || (a->N > 256 && a->K >= 1536))) return 3;
@@ -1123,7 +1129,13 @@ int pick_variant(const wj_gemm_args* a) {
 
 template <bool AT, bool BT, int EPI>
 int launch_bn(const wj_gemm_args* a, hipStream_t s) {
-    switch (pick_variant(a)) {
+    int v = pick_variant(a);
+    if (v == 4) {
+        const int rc = wj_gemm_persist_launch(a, s);
+        if (rc != WJ_ERR_UNSUPPORTED) return rc;
+        v = 3;                                   // no scheduling slot for this stream: the one-tile-per-workgroup form
+    }
+    switch (v) {
         case 1: return launch<AT, BT, EPI, 256, 0>(a, s);
         case 2: return launch<AT, BT, EPI, 256, 1>(a, s);
         case 3:

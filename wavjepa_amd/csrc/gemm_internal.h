@@ -1,0 +1,10 @@
+// Internal seam between csrc/gemm.hip (variant selection, the C ABI entry) and csrc/gemm_persist.hip (the persistent
+// eight-phase kernel).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/wavjepa_hip.h"
+
+// true when wj_gemm_persist_launch can run this problem (row-form operands, K % 128 == 0, >= 256 output tiles, a forward epilogue)
+bool wj_gemm_persist_eligible(const wj_gemm_args* a);
+// WJ_OK, or WJ_ERR_UNSUPPORTED (not eligible / no scheduling slot left for this stream: the caller takes another variant)
+int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s);

@@ -1,0 +1,636 @@
+// Persistent form of the eight-phase bf16 GEMM (variant 4 of wj_gemm_bf16): C[M,N] = A[M,K] . B[N,K]^T, row-form operands,
+// K % 128 == 0, M >= 256, N >= 256, forward epilogues (bias / erf-GELU / conv GELU).
+//
+// Why.  In the one-tile-per-workgroup kernels (csrc/gemm.hip) a 256 x 256 tile with K = 768 spends half of its life outside the
+// MFMA loop: the first operand pieces travel with nothing to hide them, the C tile goes accumulators -> LDS -> global between two
+// __syncthreads (7.5-8.6 k cycles, and it needs the ring's LDS), the workgroup retires and the next one is dispatched.  With K = 384
+// (the predictor) it is three quarters.  Here 256 workgroups (one per CU) stay resident and walk over the output tiles:
+//   * the K-tile stream never stops at a tile boundary: while the last two K tiles of output tile i are multiplied, the LDS-DMA
+//     pieces of the first two K tiles of tile i+1 are already on their way (same four-piece, one-piece-per-phase staging and the
+//     same counted vmcnt waits as eight_phase_loop in gemm.hip);
+//   * LDS-DMA addressing is scalar: `global_load_lds_dwordx4 voffset, sbase` from inline asm, where voffset (row-in-tile * ld +
+//     swizzled chunk) is a per-lane CONSTANT of the whole kernel and sbase = matrix + tile origin + k is a wave-uniform SGPR pair
+//     advanced by the scalar unit.  The K loop carries 4 address VGPRs instead of 16 and spends no VALU instruction on addresses
+//     (while the SIMD partner runs its MFMA cluster the loading wave gets one vector-issue slot per MFMA);
+//   * the epilogue works from the accumulator registers: bias, bf16 rounding, v_permlane16_swap between lane rows g and g^1 so that
+//     every lane holds 8 consecutive columns, one 16-byte store per lane (a wave-instruction writes 16 rows x 64 B).  No LDS, no
+//     barrier: each wave stores its own 128 x 64 block while its SIMD partner (one barrier ahead or behind) multiplies;
+//   * the stores are not waited for: the first K tile after an epilogue counts them into its vmcnt thresholds (they are YOUNGER than
+//     the pieces that wait retires), and by the second K tile they have drained;
+//   * edge tiles are SHIFTED, not clipped: the last tile row / column starts at M - 256 / N - 256 and recomputes a strip its
+//     neighbour also writes (same operands, same k order: the same bits).  No clamped rows, no predicated stores, every tile issues
+//     the same instruction stream -- which is what lets the vmcnt arithmetic above count on the stores;
+//   * tiles are PULLED: a workgroup's first tile is static (block id), every further one comes from an atomic counter of its XCD
+//     label (blockIdx % 8: the tiles of one A panel stay on one L2), fetched a whole tile ahead by lane 0 of wave 0 and passed to the
+//     other waves through an LDS word.  Workgroups that start late (a second stream holds their CU) simply pull fewer tiles.  Every
+//     workgroup makes exactly one failing pull, so a launch draws exactly chunk_len values from each counter and the pull that draws
+//     the last one resets it: no memset between launches, no host-side state besides a stream -> counter-slot table.
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <unordered_map>
+#include "common.h"
+#include "../../include/wavjepa_hip.h"
+#include "gemm_internal.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr unsigned BUF = 65536u, BOFF = 32768u;   // LDS: two parities of [A 256 rows | B 256 rows] x 128 B
+constexpr unsigned AUX = 131072u;                 // [2 tiles][8 waves][64 floats] bias of the wave's 64 columns
+constexpr unsigned MAILBOX = AUX + 4096u;         // next-next tile index, written by wave 0
+constexpr int LDS_TOTAL = (int)MAILBOX + 64;
+constexpr int SLOTS = 64;                         // counter sets (one per stream that launches this kernel)
+constexpr int CTR_STRIDE = 32;                    // dwords between the 8 counters of a set (one 128-B line each)
+
+__device__ unsigned g_sched_ctr[SLOTS * 8 * CTR_STRIDE];
+__device__ __attribute__((aligned(256))) unsigned char g_zero_bias[256];
+constexpr int STAMP_N = 64;
+__device__ unsigned long long g_stamps[256 * STAMP_N];   // diagnostic (WJ_PERSIST_STAMPS=1): start, end of prologue, end of every tile
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+struct PArgs {
+    const char* A;
+    const char* B;
+    char* C;
+    char* C2;
+    const float* bias;
+    unsigned* ctr;            // this launch's 8 counters
+    long ldc_b;               // bytes
+    unsigned lda_b, ldb_b;    // bytes
+    int M, N, K, tiles_n, ntiles;
+    int seg_rows, seg_valid;
+    unsigned long long* stamps;   // diagnostic: [256 workgroups][STAMP_N] s_memrealtime values (100 MHz), or NULL
+};
+
+// A value hipcc cannot relate to its source: address arithmetic built on it is redone where it is written instead of being
+// hoisted out of the tile loop and kept in registers across the MFMA phases (the loop runs at 128 accumulators + 64 fragment
+// registers per lane; hoisted tables spill to scratch, and every scratch access is a vmcnt(0) in the LDS-DMA ring).
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 B from sbase + voff (per lane) to LDS bytes [lds_wave + LDS_CONST + 16 lane).
+// M0 is written here and nowhere else in this kernel (no builtin LDS-DMA is left in it).
+template <unsigned LDS_CONST>
+__device__ __forceinline__ void dma(unsigned voff, const char* sbase, unsigned lds_wave) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 ::"v"(voff), "s"(sbase), "s"(lds_wave), "n"(LDS_CONST) : "memory", "m0", "scc");
+}
+
+// wave-uniform source bases of the next LDS-DMA of each piece (X = A rows 0-63 of each wave row, Y = rows 64-127, B0 = B rows
+// 0-31 of each wave column, B1 = rows 32-63), advanced by 128 B per K tile
+struct Bases {
+    const char* x;
+    const char* y;
+    const char* b0;
+    const char* b1;
+};
+
+// One K tile (64 deep) of the stream = four phases; see eight_phase_loop in gemm.hip for the phase / wait structure.
+//   last1: this is the last K tile of its output tile (the Y / B1 pieces staged here belong to the next output tile);
+//   last2: the next K tile is the last one (B0 / X staged here belong to the next output tile);
+//   lag:   first K tile after an epilogue: its LAG VMEM operations (stores + 1 bias DMA) sit between the awaited pieces and the
+//          ones issued here.
+//   FIRST: first PAIR of K tiles of an output tile.  In its PAR == 0 tile every accumulator's first MFMA takes the bias as C (no
+//          clearing, no bias add in the epilogue) and nothing is staged in phases 0 / 1: Y and B1 of the second K tile went out
+//          BEFORE the previous tile's epilogue, so that the waits of the first K-tile pair only retire operations older than
+//          that epilogue's stores (store acknowledgements take ~4 us under load; stores and LDS-DMA share one in-order vmcnt).
+//          Its PAR == 1 tile hands the pulled tile index to the other waves.
+template <int PAR, int LAG, bool FIRST>
+__device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s, const char* nA, const char* nB, unsigned y_skip,
+                                        unsigned b1_skip, const unsigned (&vx)[2], const unsigned (&vb)[2], const unsigned (&dx)[2],
+                                        const unsigned (&db)[2], unsigned a_lo, unsigned b_lo, bool last1, bool last2, bool has_next,
+                                        bool lag, bool mail, const unsigned& pv, const f32x4 (&bv)[4]) {
+    constexpr unsigned CUR = PAR * BUF, OTH = (PAR ^ 1) * BUF;
+    char* cur = smem + CUR;
+    const unsigned a_hi = a_lo ^ 64u, b_hi = b_lo ^ 64u;
+    if constexpr (PAR == 0) last1 = false;     // K tiles per output tile are even
+    else last2 = false;
+    const bool more1 = !last1 || has_next;
+    const bool more2 = (!last1 && !last2) || has_next;
+    bf16x8 af[8], b0f[4], b1f[4];
+    auto lds = [&](unsigned off) { return *reinterpret_cast<const bf16x8*>(cur + off); };
+    // ---- phase 0: X, B0 of this tile; stage Y(t+1); wait for B1(t)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { b0f[2 * x] = lds(b_lo + x * 2048); b0f[2 * x + 1] = lds(b_hi + x * 2048); }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { af[2 * x] = lds(a_lo + x * 2048); af[2 * x + 1] = lds(a_hi + x * 2048); }
+    if constexpr (FIRST && PAR == 0) {
+        // Y(t+1) went out before the previous epilogue (or in the prologue).  Younger than the awaited B1(t): B0, X, Y, B1 of t+1
+        // (+ the epilogue's stores and the bias DMA)
+        if (lag) wait_vmcnt<8 + LAG>();
+        else wait_vmcnt<8>();
+    } else if (more1) {
+        if constexpr (PAR == 1) {
+            if (last1) s.y = nA + y_skip;
+        }
+        dma<OTH + 8192>(vx[0], s.y, dx[0]); dma<OTH + 8192>(vx[1], s.y, dx[1]);
+        s.y += 128;
+        if constexpr (FIRST) {                 // PAR == 1: the awaited Y(t), B1(t) are OLDER than the epilogue's stores
+            if (lag) wait_vmcnt<6 + LAG>();
+            else wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<6>();
+        }
+    } else {
+        wait_vmcnt<0>();
+    }
+    if constexpr (PAR == 1 && FIRST) {
+        if (mail) {
+            // the pull issued before this output tile's first K tile is older than the pieces the wait above retired: pv has landed
+            asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tds_write_b32 %1, %0\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                         ::"v"(pv), "v"(MAILBOX) : "memory");
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[ni] : acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni + 1], af[2 * mi + 1], acc[mi][ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: B1 of this tile; stage B1(t+1)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { b1f[2 * x] = lds(b_lo + 4096 + x * 2048); b1f[2 * x + 1] = lds(b_hi + 4096 + x * 2048); }
+    if (more1 && !(FIRST && PAR == 0)) {
+        if constexpr (PAR == 1) {
+            if (last1) s.b1 = nB + b1_skip;
+        }
+        dma<OTH + BOFF + 4096>(vb[0], s.b1, db[0]); dma<OTH + BOFF + 4096>(vb[1], s.b1, db[1]);
+        s.b1 += 128;
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[2 + ni] : acc[mi][2 + ni], 0, 0, 0);
+            acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[mi][2 + ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: Y of this tile; stage B0(t+2) into THIS parity
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { af[2 * x] = lds(a_lo + 8192 + x * 2048); af[2 * x + 1] = lds(a_hi + 8192 + x * 2048); }
+    if (more2) {
+        if constexpr (PAR == 0) {
+            if (last2) s.b0 = nB;
+        }
+        dma<CUR + BOFF>(vb[0], s.b0, db[0]); dma<CUR + BOFF>(vb[1], s.b0, db[1]);
+        s.b0 += 128;
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[2 + ni] : acc[4 + mi][2 + ni], 0, 0, 0);
+            acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[4 + mi][2 + ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: no fragment reads; stage X(t+2) into THIS parity; wait for X(t+1), B0(t+1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+        if constexpr (PAR == 0) {
+            if (last2) s.x = nA;
+        }
+        dma<CUR>(vx[0], s.x, dx[0]); dma<CUR>(vx[1], s.x, dx[1]);
+        s.x += 128;
+        if constexpr (PAR == 0 && FIRST) {
+            if (lag) wait_vmcnt<8 + LAG>();
+            else wait_vmcnt<8>();
+        } else {
+            wait_vmcnt<8>();
+        }
+    } else if (more1) {
+        if constexpr (PAR == 0 && FIRST) {
+            if (lag) wait_vmcnt<4 + LAG>();
+            else wait_vmcnt<4>();
+        } else {
+            wait_vmcnt<4>();
+        }
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[ni] : acc[4 + mi][ni], 0, 0, 0);
+            acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[2 * ni + 1], af[2 * mi + 1], acc[4 + mi][ni], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 p;
+    p[0] = f2bf(a);
+    p[1] = f2bf(b);
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// lane rows g and g^1 trade halves: afterwards (x0, x1, y0, y1) are 8 consecutive columns of one output row
+__device__ __forceinline__ u32x4 widen(unsigned x0, unsigned x1, unsigned y0, unsigned y1) {
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+// Number of global stores one wave issues per output tile
+template <int EPI> struct StoreCount { static constexpr int N = (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU) ? 16 : 32; };
+
+// Lanes i and i ^ 8 of a 16-lane row trade quarters: in: w0 / w1 = this lane's 8 columns of the left / right 32-column half of its
+// row i; out: s0 = 8 columns of row (i & 7), s1 = 8 columns of row 8 + (i & 7), both in half (i >> 3).  A wave-instruction that
+// stores s0 (or s1) then writes 8 rows x 128 B -- whole cache lines.  (With the half-line form, 16 rows x 64 B per instruction,
+// the vector memory path spends its time per LINE touched: the epilogue took 4.2 us per tile instead of ~2, and the L2 had to
+// fetch every line it was handed half of.)
+__device__ __forceinline__ void fullrow(const u32x4& w0, const u32x4& w1, u32x4& s0, u32x4& s1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        s0[d] = __builtin_amdgcn_update_dpp(w0[d], w1[d], 0x128 /* row_ror:8 */, 0xF, 0xC, false);   // lanes 8-15 <- w1 of lane i - 8
+        s1[d] = __builtin_amdgcn_update_dpp(w1[d], w0[d], 0x128, 0xF, 0x3, false);                  // lanes 0-7  <- w0 of lane i + 8
+    }
+}
+
+// 16-byte non-temporal global store: the C tile is not re-read by this kernel, and kept out of the L2's way its operand panels
+// stay resident (measured with tools/persist_stamps.py: 1.30 instead of 1.37 us per K tile on the teacher's QKV shape, and
+// 0.6 us less store-acknowledge stall per tile; sc1 / sc0 sc1 write-through forms were slower than plain stores).
+__device__ __forceinline__ void store16(char* p, const u32x4& v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+}
+
+// accumulators (bias included: it was the C operand of their first MFMA) -> bf16 (-> GELU) -> 16-byte stores.
+// acc[mi][ni][r] = C[m0 + wm*128 + mi*16 + i][n0 + wn*64 + ni*16 + 4 g + r]   (i = lane & 15, g = lane >> 4)
+template <int EPI, bool FULLROW>
+__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], const PArgs& a, int m0, int n0, int wm, int wn, int lane) {
+    const int ln = opaque(lane);
+    const int i = ln & 15, g = ln >> 4;
+    // FULLROW (after widen() + fullrow()): this lane stores rows (i & 7) and 8 + (i & 7) of each 16-row block, columns
+    // wn*64 + (i >> 3)*32 + (g & 1)*16 + (g >> 1)*8 .. + 7; otherwise (after widen()): row i, those columns of both 32-column halves
+    const long lane_off = FULLROW ? (long)(i & 7) * a.ldc_b + (long)(wn * 64 + (i >> 3) * 32 + (g & 1) * 16 + (g >> 1) * 8) * 2
+                                  : (long)i * a.ldc_b + (long)(wn * 64 + (g & 1) * 16 + (g >> 1) * 8) * 2;
+    char* c1 = a.C + ((long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2) + lane_off;
+    char* c2 = nullptr;
+    if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) c2 = a.C2 + ((long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2) + lane_off;
+    int rem = 0;                                       // CONV_GELU: row % seg_rows, carried from row to row + 16 (seg_rows > 16)
+    if constexpr (EPI == WJ_EPI_CONV_GELU) rem = (m0 + wm * 128 + i) % a.seg_rows;
+    const long row8 = 8 * a.ldc_b;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        bool valid = true;
+        if constexpr (EPI == WJ_EPI_CONV_GELU) {
+            valid = rem < a.seg_valid;
+            rem += 16;
+            rem = rem >= a.seg_rows ? rem - a.seg_rows : rem;
+        }
+        u32x4 w1[2], w2[2];                             // [column half]: first output (C), second output (C2)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 va = acc[mi][2 * p], vb = acc[mi][2 * p + 1];
+            if constexpr (EPI == WJ_EPI_BF16) {
+                w1[p] = widen(pack_bf16(va[0], va[1]), pack_bf16(va[2], va[3]), pack_bf16(vb[0], vb[1]), pack_bf16(vb[2], vb[3]));
+            } else {
+                // h = bf16(acc + bias), as a bf16 linear returns it; gelu / gelu' of THAT value (nn.GELU on a bf16 tensor)
+                f32x2 h[4], gl[4], gp[4];
+                h[0] = f32x2{bf2f(f2bf(va[0])), bf2f(f2bf(va[1]))};
+                h[1] = f32x2{bf2f(f2bf(va[2])), bf2f(f2bf(va[3]))};
+                h[2] = f32x2{bf2f(f2bf(vb[0])), bf2f(f2bf(vb[1]))};
+                h[3] = f32x2{bf2f(f2bf(vb[2])), bf2f(f2bf(vb[3]))};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (EPI == WJ_EPI_BIAS_GELU2) gelu_pk<true>(h[q], gl[q], gp[q]);
+                    else gelu_pk<false>(h[q], gl[q], gp[q]);
+                }
+                if constexpr (EPI == WJ_EPI_CONV_GELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        h[q].x = valid ? h[q].x : 0.f; h[q].y = valid ? h[q].y : 0.f;
+                        gl[q].x = valid ? gl[q].x : 0.f; gl[q].y = valid ? gl[q].y : 0.f;
+                    }
+                }
+                const u32x4 og = widen(pack_bf16(gl[0].x, gl[0].y), pack_bf16(gl[1].x, gl[1].y), pack_bf16(gl[2].x, gl[2].y), pack_bf16(gl[3].x, gl[3].y));
+                if constexpr (EPI == WJ_EPI_BIAS_GELU) {
+                    w1[p] = og;
+                } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
+                    w1[p] = widen(pack_bf16(gp[0].x, gp[0].y), pack_bf16(gp[1].x, gp[1].y), pack_bf16(gp[2].x, gp[2].y), pack_bf16(gp[3].x, gp[3].y));   // C  = gelu'(h)
+                    w2[p] = og;                                                                                                                     // C2 = gelu(h)
+                } else {   // CONV_GELU: C = pre, C2 = post
+                    w1[p] = widen(pack_bf16(h[0].x, h[0].y), pack_bf16(h[1].x, h[1].y), pack_bf16(h[2].x, h[2].y), pack_bf16(h[3].x, h[3].y));
+                    w2[p] = og;
+                }
+            }
+        }
+        const long off = (long)(mi * 16) * a.ldc_b;
+        if constexpr (FULLROW) {
+            u32x4 s0, s1;
+            fullrow(w1[0], w1[1], s0, s1);
+            store16(c1 + off, s0);
+            store16(c1 + off + row8, s1);
+            if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) {
+                fullrow(w2[0], w2[1], s0, s1);
+                store16(c2 + off, s0);
+                store16(c2 + off + row8, s1);
+            }
+        } else {
+            store16(c1 + off, w1[0]);
+            store16(c1 + off + 64, w1[1]);
+            if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) {
+                store16(c2 + off, w2[0]);
+                store16(c2 + off + 64, w2[1]);
+            }
+        }
+    }
+}
+
+template <int EPI, bool FULLROW>
+__global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
+    constexpr int LAG = StoreCount<EPI>::N + 1;       // + the bias DMA of the block that precedes an output tile's first K tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n = a.K >> 6;                           // K tiles per output tile (even)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- this workgroup's queue: the logical tile ids [cstart, cstart + clen) of its XCD label (as xcd_remap deals them)
+    const int xl = blockIdx.x & 7;
+    const int qn = a.ntiles >> 3, qr = a.ntiles & 7;
+    const int clen = qn + (xl < qr ? 1 : 0);
+    const int cstart = xl < qr ? xl * (qn + 1) : qr * (qn + 1) + (xl - qr) * qn;
+    unsigned* ctr = a.ctr + xl * CTR_STRIDE;
+    unsigned pv = 0;
+    auto pull = [&]() {
+        // lane 0 of wave 0.  A returning atomic from inline asm: its result register is not tracked by hipcc's waitcnt pass (a
+        // tracked one would drain the LDS-DMA ring with vmcnt(0) at first use); it is consumed, again from asm, behind a counted
+        // wait that covers it (tools/asm_checks.py verifies that nothing touches the register in between).
+        if (wave == 0)
+            asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1"
+                         : "+v"(pv) : "v"(0u), "v"(1u), "s"(ctr) : "memory");
+    };
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (a.stamps && t == 0 && n_stamp < STAMP_N) a.stamps[blockIdx.x * STAMP_N + n_stamp] = __builtin_amdgcn_s_memrealtime();
+        ++n_stamp;
+    };
+    stamp();
+
+    // ---- piece geometry of this wave.  Two 1-KiB instructions (8 rows x 128 B) per piece: instruction u covers tile rows
+    // r_u + lane / 8, lane % 8 = LDS chunk position, holding source chunk (lane % 8) ^ ((row >> 1) & 7) (the swizzle the fragment
+    // reads undo).  dx / db: wave-uniform LDS bytes of the instruction inside the A / B region; vx / vb: per-lane source bytes
+    // relative to the tile origin (the Y / B1 pieces are 64 / 32 rows further: a scalar term).
+    unsigned dx[2], db[2], vx[2], vb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rx = (wave < 4 ? 16 * wave : 128 + 16 * (wave - 4)) + 8 * u;
+        const int ib = 16 * wave + 8 * u, rb = (ib >> 5) * 64 + (ib & 31);
+        dx[u] = lds0 + (unsigned)rx * 128u;
+        db[u] = lds0 + (unsigned)rb * 128u;
+        const int rowx = rx + (lane >> 3), rowb = rb + (lane >> 3);
+        vx[u] = (unsigned)rowx * a.lda_b + (unsigned)(((lane & 7) ^ ((rowx >> 1) & 7)) * 16);
+        vb[u] = (unsigned)rowb * a.ldb_b + (unsigned)(((lane & 7) ^ ((rowb >> 1) & 7)) * 16);
+    }
+    const unsigned y_skip = 64u * a.lda_b, b1_skip = 32u * a.ldb_b;
+    auto tile_coords = [&](int q, int& m0, int& n0) {
+        const int L = cstart + q;
+        const int tm = L / a.tiles_n;
+        m0 = min(tm * 256, a.M - 256);                 // edge tiles are shifted inwards
+        n0 = min((L - tm * a.tiles_n) * 256, a.N - 256);
+    };
+    const char* bias_src = a.bias ? reinterpret_cast<const char*>(a.bias) : reinterpret_cast<const char*>(g_zero_bias);
+    auto bias_dma = [&](int n0, int slot) {
+        // this wave's 64 bias values -> its LDS slot: lanes 0-15, 16 B each
+        const int ln = opaque(lane);
+        const unsigned bias_v = a.bias ? (unsigned)((wn * 64 + (ln & 15) * 4) * 4) : (unsigned)((ln & 15) * 16);
+        const char* sb = a.bias ? bias_src + (long)n0 * 4 : bias_src;
+        const unsigned dst = lds0 + AUX + (unsigned)(slot * 2048 + wave * 256);
+        asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffff\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                     ::"v"(bias_v), "s"(sb), "s"(dst) : "memory", "m0");
+    };
+
+    f32x4 acc[8][4];                                   // defined by the first K tile of every output tile (C = 0 there)
+
+    // ---- prologue: first tile is static; pull the second
+    int m0, n0;
+    tile_coords(blockIdx.x >> 3, m0, n0);
+    Bases s;
+    s.x = a.A + (long)m0 * a.lda_b;
+    s.y = s.x + y_skip;
+    s.b0 = a.B + (long)n0 * a.ldb_b;
+    s.b1 = s.b0 + b1_skip;
+    bias_dma(n0, 0);
+    pull();
+    dma<0>(vx[0], s.x, dx[0]); dma<0>(vx[1], s.x, dx[1]);
+    dma<BOFF>(vb[0], s.b0, db[0]); dma<BOFF>(vb[1], s.b0, db[1]);
+    dma<8192>(vx[0], s.y, dx[0]); dma<8192>(vx[1], s.y, dx[1]);
+    dma<BOFF + 4096>(vb[0], s.b1, db[0]); dma<BOFF + 4096>(vb[1], s.b1, db[1]);
+    s.x += 128; s.b0 += 128; s.y += 128; s.b1 += 128;
+    dma<BUF + BOFF>(vb[0], s.b0, db[0]); dma<BUF + BOFF>(vb[1], s.b0, db[1]);
+    dma<BUF>(vx[0], s.x, dx[0]); dma<BUF>(vx[1], s.x, dx[1]);
+    dma<BUF + 8192>(vx[0], s.y, dx[0]); dma<BUF + 8192>(vx[1], s.y, dx[1]);
+    dma<BUF + BOFF + 4096>(vb[0], s.b1, db[0]); dma<BUF + BOFF + 4096>(vb[1], s.b1, db[1]);
+    s.x += 128; s.b0 += 128; s.y += 128; s.b1 += 128;
+    wait_vmcnt<8>();                                   // K tile 0's pieces, the bias and the pull (all older) have landed
+    if (wave == 0)
+        asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tds_write_b32 %1, %0\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                     ::"v"(pv), "v"(MAILBOX) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned mail_v = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
+    mail_v = __builtin_amdgcn_readfirstlane(mail_v);
+    if (mail_v == (unsigned)(clen - 1) && t == 0) atomicExch(ctr, 0u);   // the launch's last pull on this counter: reset it
+    int q_next = 32 + (int)mail_v;
+    bool has_next = q_next < clen;
+
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned sw = (unsigned)((g ^ ((i >> 1) & 7)) << 4);
+    const unsigned a_lo = (unsigned)((wm * 128 + i) * 128) + sw;
+    const unsigned b_lo = BOFF + (unsigned)((wn * 64 + i) * 128) + sw;
+    stamp();
+    if (wm == 1) __builtin_amdgcn_s_barrier();        // waves 4-7 run one barrier behind
+
+    bool lag = false;
+    int slot = 0;
+    for (;;) {
+        // ---- before the first K tile of an output tile: where the next one starts, its bias, and the pull for the one after
+        int m1 = m0, n1 = n0;
+        const bool pulled = has_next;
+        const char* nA = a.A;
+        const char* nB = a.B;
+        if (has_next) {
+            tile_coords(q_next, m1, n1);
+            nA = a.A + (long)m1 * a.lda_b;
+            nB = a.B + (long)n1 * a.ldb_b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bias_dma(n1, slot ^ 1);                        // always exactly one DMA here (the LAG count relies on it)
+        if (pulled) pull();
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 bv[4];                                   // bias of this lane's 16 columns: the accumulators start from it
+        {
+            const int g = opaque(lane) >> 4;
+            const char* bs = smem + AUX + slot * 2048 + wave * 256;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 64 + g * 16);
+        }
+        pp_tile<0, LAG, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, 2 == n, has_next, lag, false, pv,
+                              bv);
+        pp_tile<1, LAG, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, 2 == n, false, has_next, lag,
+                              pulled && wave == 0, pv, bv);
+        stamp();                                       // diagnostic: end of the first two K tiles
+        for (int kt = 2; kt < n; kt += 2) {
+            pp_tile<0, LAG, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, kt + 2 == n, has_next, false,
+                                   false, pv, bv);
+            pp_tile<1, LAG, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, kt + 2 == n, false, has_next, false,
+                                   false, pv, bv);
+        }
+        if (has_next) {
+            // Y, B1 of the next tile's SECOND K tile, before this tile's stores (see FIRST above).  Their slots (odd parity) were last
+            // read in phases 1 / 2 of the K tile just finished, by a wave group that is past those phases whichever group asks.
+            dma<BUF + 8192>(vx[0], s.y, dx[0]); dma<BUF + 8192>(vx[1], s.y, dx[1]);
+            dma<BUF + BOFF + 4096>(vb[0], s.b1, db[0]); dma<BUF + BOFF + 4096>(vb[1], s.b1, db[1]);
+            s.y += 128; s.b1 += 128;
+        }
+        // ---- epilogue from the registers
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();                                       // diagnostic: end of the K loop
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA results of the last phase -> VALU readers behind the loop branch
+        epilogue_regs<EPI, FULLROW>(acc, a, m0, n0, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if (!has_next) break;
+        lag = true;                                    // every tile issues all of its stores (edge tiles are shifted, not clipped)
+        m0 = m1; n0 = n1;
+        slot ^= 1;
+        if (pulled) {
+            // the word wave 0 wrote in the second K tile of the tile just finished (>= 6 barriers ago for either wave group; the next
+            // write is a K tile away)
+            unsigned mv = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
+            mv = __builtin_amdgcn_readfirstlane(mv);
+            if (mv == (unsigned)(clen - 1) && t == 0) atomicExch(ctr, 0u);
+            q_next = 32 + (int)mv;
+            has_next = q_next < clen;
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger
+}
+
+struct SlotTable {
+    std::mutex mu;
+    std::unordered_map<hipStream_t, int> slots;
+    unsigned* base = nullptr;
+};
+SlotTable& table() {
+    static SlotTable t;
+    return t;
+}
+
+template <int EPI>
+int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr) {
+    PArgs p;
+    p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C; p.C2 = (char*)a->C2; p.bias = (const float*)a->bias;
+    p.ctr = ctr;
+    p.ldc_b = a->ldc * 2; p.lda_b = (unsigned)(a->lda * 2); p.ldb_b = (unsigned)(a->ldb * 2);
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.tiles_n = (a->N + 255) / 256;
+    p.ntiles = ((a->M + 255) / 256) * p.tiles_n;
+    p.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1;
+    p.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
+    {
+        static int stamps = -1;                     // WJ_PERSIST_STAMPS=1: diagnostic time stamps (tools/persist_stamps.py)
+        if (stamps < 0) { const char* v = getenv("WJ_PERSIST_STAMPS"); stamps = v ? atoi(v) : 0; }
+        p.stamps = nullptr;
+        if (stamps) {
+            void* sp = nullptr;
+            if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_stamps)) == hipSuccess) p.stamps = (unsigned long long*)sp;
+        }
+    }
+    // (measured: whole-line stores are worth 1-3 % on the teacher's shapes and 7 % on 8192^3 over 16 rows x 64 B per instruction)
+    auto kern = gemm_persist_kernel<EPI, true>;
+    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // once per kernel
+    if (attr != hipSuccess) return WJ_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(NT), LDS_TOTAL, s, p);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+}  // namespace
+
+bool wj_gemm_persist_eligible(const wj_gemm_args* a) {
+    if (a->a_trans || a->b_trans || a->rowmap || a->colsum || a->split_k > 1) return false;
+    if (a->K < 128 || (a->K % 128) || a->M < 256 || a->N < 256) return false;
+    const int e = a->epilogue;
+    if (e != WJ_EPI_BF16 && e != WJ_EPI_BIAS_GELU2 && e != WJ_EPI_BIAS_GELU && e != WJ_EPI_CONV_GELU) return false;
+    if ((e == WJ_EPI_BIAS_GELU2 || e == WJ_EPI_CONV_GELU) && !a->C2) return false;
+    if (e == WJ_EPI_CONV_GELU && a->seg_rows > 0 && a->seg_rows <= 16) return false;
+    const long tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    if (tiles < 256) return false;
+    if (a->lda * 2 * 256 >= (1l << 31) || a->ldb * 2 * 256 >= (1l << 31)) return false;   // 32-bit per-lane offsets inside a tile
+    return true;
+}
+
+// diagnostic: copy the stamp buffer to the host (synchronises the device)
+extern "C" int wj_debug_persist_stamps(unsigned long long* out, int n) {
+    if (!out || n <= 0) return WJ_ERR_ARG;
+    if (n > 256 * STAMP_N) n = 256 * STAMP_N;
+    if (hipDeviceSynchronize() != hipSuccess) return WJ_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8) != hipSuccess) return WJ_ERR_LAUNCH;
+    return WJ_OK;
+}
+
+int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
+    if (!wj_gemm_persist_eligible(a)) return WJ_ERR_UNSUPPORTED;
+    SlotTable& T = table();
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(T.mu);
+        if (!T.base) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_ctr)) != hipSuccess) { (void)hipGetLastError(); return WJ_ERR_UNSUPPORTED; }
+            T.base = (unsigned*)p;
+        }
+        auto it = T.slots.find(s);
+        if (it == T.slots.end()) {
+            if ((int)T.slots.size() >= SLOTS) return WJ_ERR_UNSUPPORTED;
+            it = T.slots.emplace(s, (int)T.slots.size()).first;
+        }
+        slot = it->second;
+    }
+    unsigned* ctr = T.base + (size_t)slot * 8 * CTR_STRIDE;
+    switch (a->epilogue) {
+        case WJ_EPI_BF16: return launch_persist<WJ_EPI_BF16>(a, s, ctr);
+        case WJ_EPI_BIAS_GELU2: return launch_persist<WJ_EPI_BIAS_GELU2>(a, s, ctr);
+        case WJ_EPI_BIAS_GELU: return launch_persist<WJ_EPI_BIAS_GELU>(a, s, ctr);
+        case WJ_EPI_CONV_GELU: return launch_persist<WJ_EPI_CONV_GELU>(a, s, ctr);
+        default: return WJ_ERR_UNSUPPORTED;
+    }
+}
