@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""A GEMM as the step sees it (GPU box): operands NOT resident in the Infinity Cache.  Every timed launch follows a 768 MB write to
+an unrelated buffer; compared with back-to-back (warm) launches.  usage: gemm_cold.py [variant ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wavjepa_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+SHAPES = [(51200, 2304, 768, ops.EPI_BF16), (51200, 768, 3072, ops.EPI_BF16), (51200, 768, 768, ops.EPI_BF16),
+          (51200, 3072, 768, ops.EPI_BIAS_GELU), (86317, 1536, 384, ops.EPI_BIAS_GELU2), (86317, 1152, 384, ops.EPI_BF16)]
+variants = [int(v) for v in sys.argv[1:]] or [3, 4]
+junk = torch.empty(768 * 1024 * 1024 // 4, device=dev)
+for (M, N, K, epi) in SHAPES:
+    A = torch.randn(M, K, device=dev).to(bf)
+    W = (torch.randn(N, K, device=dev) * 0.05).to(bf)
+    C = torch.empty(M, N, device=dev, dtype=bf)
+    C2 = torch.empty(M, N, device=dev, dtype=bf) if epi == ops.EPI_BIAS_GELU2 else None
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=epi, bias=torch.randn(N, device=dev))
+    if C2 is not None:
+        kw["C2"] = C2
+    out = []
+    for v in variants:
+        ops.gemm_set_variant(v)
+        res = {}
+        for mode in ("warm", "cold"):
+            ts = []
+            for r in range(8):
+                if mode == "cold":
+                    junk.fill_(float(r))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.gemm(A, W, C, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                if r > 1:
+                    ts.append(e0.elapsed_time(e1) * 1e3)
+            res[mode] = sorted(ts)[len(ts) // 2]
+        out.append(f"variant {v}: warm {res['warm']:7.1f} us, cold {res['cold']:7.1f} us")
+    print(f"M={M} N={N} K={K} epi={epi}: " + " | ".join(out))
+ops.gemm_set_variant(-1)

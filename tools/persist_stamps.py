@@ -40,6 +40,8 @@ for (M, Nn, K, epi) in SHAPES:
     rc = lib.wj_debug_persist_stamps(buf.ctypes.data, 256 * N)
     assert rc == 0
     s = buf.reshape(256, N).astype(np.int64)
+    clk = s[:, N - 2:].copy()
+    s[:, N - 2:] = 0
     t0 = s[:, 0].min()
     # stamps: [start, prologue end, then per tile: after first K-tile pair, end of K loop, end of epilogue]
     det = s[:, 2:2 + 3 * 6].reshape(256, 6, 3)
@@ -47,6 +49,9 @@ for (M, Nn, K, epi) in SHAPES:
     pair = (det[:, 1:5, 0] - prev_end[:, 1:5]) / 100.0                      # tiles 1..4: first two K tiles after an epilogue
     rest = (det[:, 1:5, 1] - det[:, 1:5, 0]) / 100.0
     epi_t = (det[:, 1:5, 2] - det[:, 1:5, 1]) / 100.0
+    last_rt = np.array([s[w, :N - 2][s[w, :N - 2] > 0].max() for w in range(256)])
+    ghz = (clk[:, 1] - clk[:, 0]) / np.maximum(1, (last_rt - s[:, 1])) / 10.0
+    print(f"   shader clock between the prologue and the last stamp: median {np.median(ghz):.3f} GHz (min {ghz.min():.3f}, max {ghz.max():.3f})")
     print(f"   tiles 1-4 (median over WGs): first K-tile pair {np.median(pair):.2f} us, rest of K loop {np.median(rest):.2f} us "
           f"({np.median(rest) / max(1, K // 64 - 2):.3f} us/K-tile), epilogue issue {np.median(epi_t):.2f} us")
     s = np.concatenate([s[:, :2], s[:, 4::3]], axis=1)                      # keep [start, prologue, tile ends] for the summary below

@@ -399,7 +399,11 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     };
     int n_stamp = 0;
     auto stamp = [&]() {
-        if (a.stamps && t == 0 && n_stamp < STAMP_N) a.stamps[blockIdx.x * STAMP_N + n_stamp] = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && t == 0 && n_stamp < STAMP_N - 2) {
+            a.stamps[blockIdx.x * STAMP_N + n_stamp] = __builtin_amdgcn_s_memrealtime();
+            if (n_stamp == 1) a.stamps[blockIdx.x * STAMP_N + STAMP_N - 2] = __builtin_amdgcn_s_memtime();      // shader clock after the prologue ...
+            a.stamps[blockIdx.x * STAMP_N + STAMP_N - 1] = __builtin_amdgcn_s_memtime();                          // ... and at the latest stamp
+        }
         ++n_stamp;
     };
     stamp();
