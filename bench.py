@@ -17,7 +17,14 @@ Prints ONE JSON line (rank 0).  Besides the contract fields it carries
                sample (N=4 clips; tiny and base models; fp32 and the bf16-autocast flow; all cores; 3 warm-up + 5 timed steps,
                median; ~45 s budget) -- a reported baseline, not the target;
   dense_ms_per_step  the same step with the reference's dense key-masked shapes, timed in this run (5 steps);
-  replicas_equal     (N > 1) every rank ends the run with bit-identical parameters.
+  replicas_equal     (N > 1) every rank ends the run with bit-identical parameters;
+  allreduce          (N > 1, or one rank under torch.distributed.run) how long the gradient buckets had to travel while the
+                     backward still ran, and how long the optimiser then still waited for them (HIP events, median over the
+                     timed steps).
+Everything after the timed region (dense-shape block, replica check, instrumented step, CPU baseline) is optional: a failure
+there is reported on stderr and as a null field; the JSON line is printed regardless.  A watchdog thread ends the process with
+exit code 3 (after printing where every stage stood) if the whole run exceeds WJ_BENCH_LIMIT_S seconds (default 900): a stalled
+collective must not hang the launch.
 """
 from __future__ import annotations
 
@@ -67,20 +74,32 @@ def gemm_kernel_name(f) -> str:
     return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
 
 
+PMC_FILES = ["r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
+
+
+def pmc_traffic_path():
+    for f in PMC_FILES:
+        if os.path.exists(os.path.join(ROOT, "profiles", f)):
+            return os.path.join(ROOT, "profiles", f)
+    return None
+
+
 def pmc_traffic_for(name: str):
-    """HBM bytes per launch of a GEMM class from the committed PMC summary (profiles/r02_pmc_traffic.json, collected with
-    tools/pmc_traffic.py on this same command): launch-weighted mean over the tile variants of the class, or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of a GEMM class from the newest committed PMC summary (profiles/rNN_pmc_traffic.json, collected with
+    tools/pmc_traffic.py on this same command in two separate rocprofv3 --pmc passes): launch-weighted mean over the tile variants
+    of the class, or None.  NOT measured by this run: the line says so in `traffic_source`."""
+    path = pmc_traffic_path()
+    if path is None:
+        return None
     m = __import__("re").match(r"gemm_kernel<([NT])([NT]),(\w+)>", name)
     if not m or not os.path.exists(path):
         return None
     epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5}[m.group(3)]
     prefix = f"gemm3_kernel<{'true' if m.group(1) == 'T' else 'false'}, {'true' if m.group(2) == 'T' else 'false'}, {epi},"
+    persist = f"gemm_persist_kernel<{6 if m.group(3) == 'BIAS_GELU' else epi},"       # the persistent variant of the forward shapes
     with open(path) as fh:
         kernels = json.load(fh)["kernels"]
-    hits = [v for k, v in kernels.items() if k.startswith(prefix)]
+    hits = [v for k, v in kernels.items() if k.startswith(prefix) or (m.group(1) == "N" and m.group(2) == "N" and k.startswith(persist))]
     n = sum(v["launches"] for v in hits)
     return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
 
@@ -243,6 +262,22 @@ def main():
     from wavjepa_amd.masking import TimeInverseBlockMasker
     from wavjepa_amd.trainer import StepRunner, init_distributed
 
+    stage = {"name": "start", "t": time.perf_counter()}
+
+    def watchdog():
+        import threading
+        limit = float(os.environ.get("WJ_BENCH_LIMIT_S", "900"))
+
+        def run():
+            t_start = time.perf_counter()
+            while time.perf_counter() - t_start < limit:
+                time.sleep(2.0)
+            print(f"[bench rank {os.environ.get('RANK', '0')}] exceeded {limit:.0f} s; last stage entered: {stage['name']} "
+                  f"({time.perf_counter() - stage['t']:.0f} s ago) -- exiting with code 3", file=sys.stderr, flush=True)
+            os._exit(3)
+        threading.Thread(target=run, daemon=True).start()
+
+    watchdog()
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -274,20 +309,36 @@ def main():
     t_begin = time.perf_counter()
 
     def note(msg):
+        stage["name"], stage["t"] = msg, time.perf_counter()
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_begin:.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    def optional(what, fn):
+        """Legs after the timed region: never lose the JSON line over them."""
+        try:
+            return fn()
+        except BaseException as e:                      # noqa: BLE001  (SystemExit of a check included: reported, not fatal)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            print(f"[bench rank {rank}] optional leg '{what}' failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            return None
+
     step_idx = 0
+    note("warm-up")
     for _ in range(args.warmup):
         runner.step(source.next_batch(), step_idx)
         step_idx += 1
     sync()
+    note("timed region")
+    runner.reducer.timing = runner.reducer.active
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = runner.step(source.next_batch(), step_idx)
         step_idx += 1
     sync()
     elapsed = time.perf_counter() - t0
+    runner.reducer.timing = False
+    allreduce = runner.reducer.timing_summary()
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -300,38 +351,56 @@ def main():
          f"{getattr(model._engine, '_stream_probe', None)}")
     # the same step with the reference's dense key-masked shapes (every token of the student / predictor computed), timed in the
     # same run so that the dense-shape rate is measured here too, not only reported
+    def dense_block():
+        nonlocal step_idx
+        model._engine.ragged = False
+        try:
+            for _ in range(2):
+                runner.step(source.next_batch(), step_idx); step_idx += 1
+            sync()
+            td = time.perf_counter()
+            for _ in range(args.dense_steps):
+                runner.step(source.next_batch(), step_idx); step_idx += 1
+            sync()
+            ms = (time.perf_counter() - td) / args.dense_steps * 1000
+            if dist.is_initialized():
+                t = torch.tensor([ms], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t)
+            return ms
+        finally:
+            model._engine.ragged = True
+
     dense_ms = None
     if args.dense_steps > 0 and model._engine.ragged:
-        model._engine.ragged = False
-        for _ in range(2):
-            runner.step(source.next_batch(), step_idx); step_idx += 1
-        sync()
-        td = time.perf_counter()
-        for _ in range(args.dense_steps):
-            runner.step(source.next_batch(), step_idx); step_idx += 1
-        sync()
-        dense_ms = (time.perf_counter() - td) / args.dense_steps * 1000
-        if dist.is_initialized():
-            t = torch.tensor([dense_ms], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dense_ms = float(t)
-        model._engine.ragged = True
-        note(f"dense-shape block done: {dense_ms:.1f} ms/step")
+        note("dense-shape block")
+        dense_ms = optional("dense-shape block", dense_block)
+        if dense_ms is not None:
+            note(f"dense-shape block done: {dense_ms:.1f} ms/step")
     # data-parallel self-check: after the same number of identical optimiser steps every rank must hold the same parameters
     flat = model._flat
     checksum = torch.stack([flat.p32.double().sum(), flat.p32.double().abs().sum(), flat.t32.double().abs().sum()])
     replicas_equal = None
-    if dist.is_initialized():
+    diverged = None
+
+    def replica_check():
         gathered = [torch.empty_like(checksum) for _ in range(world)]
         dist.all_gather(gathered, checksum)
-        replicas_equal = all(torch.equal(gathered[0], g) for g in gathered)
-        if not replicas_equal:
-            raise SystemExit(f"data-parallel replicas diverged: parameter checksums per rank {[g.tolist() for g in gathered]}")
+        return gathered
+
+    if dist.is_initialized():
+        note("replica check")
+        gathered = optional("replica check", replica_check)
+        if gathered is not None:
+            replicas_equal = all(torch.equal(gathered[0], g) for g in gathered)
+            if not replicas_equal:
+                diverged = f"data-parallel replicas diverged: parameter checksums per rank {[g.tolist() for g in gathered]}"
     roofline = None
     classes = {}
     executed_gflop = None
     if not args.no_profile:
-        classes = profile_one_step(runner, source, step_idx)
+        note("instrumented step")
+        classes = optional("instrumented step", lambda: profile_one_step(runner, source, step_idx)) or {}
         gemms = {k: v for k, v in classes.items() if v["flops"] > 0}
         executed_gflop = sum(v["flops"] for v in gemms.values()) / 1e9      # GEMM flops one step actually executes
         if gemms:
@@ -347,7 +416,10 @@ def main():
             all_fl = sum(v["flops"] for v in gemms.values())
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
-                            frac=round(ach / peak, 4), traffic=None if fp8 else pmc_traffic_for(name), launches_per_step=c["launches"],
+                            frac=round(ach / peak, 4), traffic=None if fp8 else optional("pmc summary", lambda: pmc_traffic_for(name)),
+                            traffic_source=None if fp8 or pmc_traffic_path() is None else
+                            f"profiles/{os.path.basename(pmc_traffic_path())} (rocprofv3 --pmc passes of this command, committed; not collected by this run)",
+                            launches_per_step=c["launches"],
                             avg_launch_ms=round(c["ms"] / c["launches"], 4),
                             gflop_per_launch=round(c["flops"] / c["launches"] / 1e9, 2),
                             algorithmic_bytes_per_launch=int(c["bytes"] / c["launches"]),   # operands once + outputs (+ addends)
@@ -378,10 +450,12 @@ def main():
             "model_tflops_per_gpu": None if executed_gflop is None else round(executed_gflop / (elapsed / args.steps) / 1000, 1),
             # dense model FLOPs exactly as the reference computes them (283.7 GFLOP per clip and step), independent
             # of the rows the ragged execution does not compute -- the rate a dense-shape implementation would need to keep up
-            "model_tflops_per_gpu_dense_equiv": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1) if seconds < 3 and not nat else None,
+            # -- NOT a utilisation figure: most of those FLOPs are not executed (ragged execution)
+            "dense_equivalent_rate_tflops": round(value / world * STEP_GFLOP_PER_CLIP / 1000, 1) if seconds < 3 and not nat else None,
             # the same step computed with the reference's dense shapes (WJ_RAGGED=0 equivalent), this run
             "dense_ms_per_step": None if dense_ms is None else round(dense_ms, 2),
             "dense_clips_per_s": None if dense_ms is None else round(args.clips_per_gpu * world / (dense_ms / 1000), 1),
+            "allreduce": allreduce,
             "replicas_equal": replicas_equal, "param_checksum": [float(v) for v in checksum.tolist()],
             "final_loss": round(loss, 5),
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
@@ -389,7 +463,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             note("instrumented step done; timing the CPU oracle")
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = optional("cpu baseline", cpu_baseline)
             note("cpu baseline done")
         print(json.dumps(line), flush=True)
         if classes:
@@ -403,8 +477,9 @@ def main():
                 json.dump({k: dict(ms=round(v["ms"], 3), launches=v["launches"], us_per_launch=round(v["ms"] / v["launches"] * 1e3, 1),
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in shapes}, fh, indent=1)
     if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        optional("final barrier", lambda: (dist.barrier(), dist.destroy_process_group()))
+    if diverged:
+        raise SystemExit(diverged)          # after the line: the record exists, the exit code says the run is invalid
 
 
 if __name__ == "__main__":

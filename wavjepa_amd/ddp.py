@@ -58,6 +58,12 @@ class FlatGradAllReducer:
         # a process group of size 1 (torch.distributed.run --nproc-per-node 1) still runs every collective: the single-GPU
         # box exercises exactly the code path the 8-GPU launch uses
         self.active = dist.is_initialized()
+        # optional timing (bench.py): HIP events on the compute stream at the first bucket's issue, at the end of the backward
+        # (= entry of wait()) and behind the last handle's wait -- (done - backward end) is the part of the all-reduce the
+        # backward did NOT hide, (backward end - first issue) the window the buckets had to travel in
+        self.timing = False
+        self.timeline: List[Tuple] = []
+        self._t_first = None
 
     def broadcast_parameters(self) -> None:
         """Rank 0's student, teacher and optimiser-visible state to everyone (DDP constructor broadcast)."""
@@ -89,10 +95,34 @@ class FlatGradAllReducer:
         flat = self.module._flat
         if self._ranges is None:
             self._ranges = section_ranges(flat, self.module.encoder.num_layers, self.enc_chunk)
+        if self.timing and self._t_first is None:
+            import torch
+            self._t_first = torch.cuda.Event(enable_timing=True)
+            self._t_first.record()
         for lo, hi in self._ranges.get(tag, []):
             self.handles.append(dist.all_reduce(flat.g32[lo:hi], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
 
     def wait(self) -> None:
+        t_end = t_done = None
+        if self.timing and self.handles:
+            import torch
+            t_end, t_done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_end.record()
         for h in self.handles:
             h.wait()          # stream-level dependency; does not block the host
+        if t_done is not None:
+            t_done.record()
+            self.timeline.append((self._t_first, t_end, t_done))
+            self._t_first = None
         self.handles = []
+
+    def timing_summary(self):
+        """Median over the recorded steps (call after a device synchronisation): ms between the first bucket's issue and the end
+        of the backward, and ms the optimiser then still waited for the collectives."""
+        if not self.timeline:
+            return None
+        win = sorted(a.elapsed_time(b) for a, b, _ in self.timeline if a is not None)
+        exp = sorted(b.elapsed_time(c) for _, b, c in self.timeline)
+        n_buckets = sum(len(v) for v in (self._ranges or {}).values())
+        return dict(buckets=n_buckets, bytes=int(self.module._flat.n) * 4, steps=len(exp),
+                    backward_window_ms=round(win[len(win) // 2], 3) if win else None, exposed_ms=round(exp[len(exp) // 2], 3))

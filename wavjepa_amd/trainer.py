@@ -4,7 +4,9 @@ at `gradient_clip_val`, per-step LR scheduler, EMA inside training_step, periodi
 Lightning checkpoint keys (`state_dict`, `hyper_parameters`, `global_step`)."""
 from __future__ import annotations
 
+import datetime
 import os
+import sys
 import time
 from typing import Any, Dict, Iterable, Optional
 
@@ -12,6 +14,17 @@ import torch
 import torch.distributed as dist
 
 from .ddp import FlatGradAllReducer
+
+
+def heartbeat(msg: str) -> None:
+    """One line per rank on stderr at every stage of a multi-rank start (rendezvous, broadcast, first collective): when an N-rank
+    launch stalls, the last line of each rank says where.  WJ_HEARTBEAT=0 silences it."""
+    if os.environ.get("WJ_HEARTBEAT", "1") != "0" and "RANK" in os.environ:
+        print(f"[rank {os.environ.get('RANK')}/{os.environ.get('WORLD_SIZE')} pid {os.getpid()} +{time.perf_counter() - _T0:.1f}s] {msg}",
+              file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def init_distributed() -> tuple:
@@ -30,14 +43,20 @@ def init_distributed() -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
+        # a collective that does not complete inside the bound aborts the process (non-zero exit) instead of hanging the launch:
+        # WJ_DIST_TIMEOUT_S, default 300 s (the first RCCL collective builds its rings / loads kernels: tens of seconds at most)
+        timeout = datetime.timedelta(seconds=float(os.environ.get("WJ_DIST_TIMEOUT_S", "300")))
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        heartbeat(f"rendezvous at {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} (backend {backend}, device {local})")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
         else:
             if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
                 # gloo binds to the interface the HOSTNAME resolves to; container hostnames often do not resolve (or do after a resolver
                 # time-out): a one-node run stays on the loopback interface
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        heartbeat("process group up")
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, local, world
@@ -51,6 +70,10 @@ class StepRunner:
         model._ensure_engine()
         self.reducer = FlatGradAllReducer(model, enc_chunk=enc_chunk)
         self.reducer.broadcast_parameters()
+        if self.reducer.active:
+            torch.cuda.synchronize()
+            heartbeat("parameters broadcast from rank 0")
+        self._first_step_done = False
         self.sectioned = hasattr(model, "_grads_ready_hook")      # JEPA: bucketed all-reduces launched from the backward's hooks
         if self.sectioned:
             model._grads_ready_hook = self.reducer.hook if self.reducer.active else None
@@ -70,6 +93,11 @@ class StepRunner:
         self.optimizer.step()                               # fused global-norm clip + AdamW over the flat buffers
         self.scheduler.step()
         m.global_step += 1
+        if not self._first_step_done:
+            self._first_step_done = True
+            if self.reducer.active:
+                torch.cuda.synchronize()
+                heartbeat("first optimisation step (all gradient buckets reduced) done")
         return out
 
 
@@ -96,10 +124,18 @@ class Trainer:
     def log_dict(self, data: Dict[str, Any], **kw) -> None:
         self.logged = data          # kept on the device: no per-step host sync / scalar all-reduce
 
-    def save_checkpoint(self, model, runner: StepRunner, path: str) -> None:
+    def save_checkpoint(self, model, runner: StepRunner, path: str, versioned: bool = False) -> None:
+        """`versioned`: never overwrite (Lightning's enable_version_counter): last.ckpt, last-v1.ckpt, ... -- the run directory is
+        the reference's run-identity directory, where an earlier run's (or a reference run's) last.ckpt may already sit."""
         if self.rank != 0:
             return
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        if versioned and os.path.exists(path):
+            stem, ext = os.path.splitext(path)
+            v = 1
+            while os.path.exists(f"{stem}-v{v}{ext}"):
+                v += 1
+            path = f"{stem}-v{v}{ext}"
         torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                     "hyper_parameters": dict(model.hparams), "global_step": model.global_step,
                     "optimizer": runner.optimizer.state_dict(), "lr_scheduler": runner.scheduler.state_dict()}, path)
@@ -125,17 +161,21 @@ class Trainer:
                 break
             out = runner.step(batch, model.global_step)
             gs = model.global_step
+            if self.log_every_n_steps and gs % self.log_every_n_steps == 0:
+                lt = out["loss"].detach().float().clone()
+                if dist.is_initialized() and self.world > 1:
+                    dist.all_reduce(lt, op=dist.ReduceOp.AVG)   # the reference logs with sync_dist=True (jepa.py:328): the rank mean
             if self.log_every_n_steps and gs % self.log_every_n_steps == 0 and self.rank == 0:
-                loss = float(out["loss"].detach())   # the only host sync, every n steps
+                loss = float(lt)                      # the only host sync, every n steps
                 dt = time.time() - t0
                 ema = f"  ema {model._get_ema_decay():.6f}" if hasattr(model, "_get_ema_decay") else ""
                 print(f"step {gs}  loss {loss:.5f}  lr {runner.scheduler.get_last_lr()[0]:.3e}{ema}  "
                       f"{dt / self.log_every_n_steps * 1000:.1f} ms/step", flush=True)
                 t0 = time.time()
             if self.root and self.ckpt_every and gs % self.ckpt_every == 0:
-                self.save_checkpoint(model, runner, os.path.join(self.root, f"step={gs}.ckpt"))
+                self.save_checkpoint(model, runner, os.path.join(self.root, f"step={gs}.ckpt"), versioned=ckpt_path is None)
         if self.root:
-            self.save_checkpoint(model, runner, os.path.join(self.root, "last.ckpt"))
+            self.save_checkpoint(model, runner, os.path.join(self.root, "last.ckpt"), versioned=ckpt_path is None)
         if self.rank == 0 and self.log_every_n_steps:
             print(f"done: {model.global_step} steps, peak HBM {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB allocated, "
                   f"{torch.cuda.max_memory_reserved(dev) / 2**30:.1f} GiB reserved", flush=True)
