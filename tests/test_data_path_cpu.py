@@ -168,6 +168,48 @@ def test_flac_decoder_under_address_and_undefined_behaviour_sanitizers(tmp_path)
     assert "mutations decoded" in r.stdout
 
 
+def test_shuffle_buffer_holds_raw_samples_and_starts_early(tmp_path):
+    """The reference shuffles the raw tar samples BEFORE decode / map (webdataset .shuffle(1000) ahead of .decode): the buffer must hold
+    bytes, give its first sample after `initial` reads, grow to `shuffle`, cover the corpus, and unreadable shards must raise."""
+    import random
+    from wavjepa_amd.data_modules.WebAudioDataModule import raw_samples
+    shards = []
+    for sh in range(3):
+        path = tmp_path / f"s{sh}.tar"
+        with tarfile.open(path, "w") as tf:
+            for i in range(40):
+                data = E.encode(tone_pcm(64, 1, 16, seed=sh * 100 + i), 16000, 16, blocksize=64)
+                info = tarfile.TarInfo(f"clip{sh}_{i:03d}.flac")
+                info.size = len(data)
+                tf.addfile(info, io.BytesIO(data))
+        shards.append(str(path))
+    reads = []
+    import wavjepa_amd.data_modules.WebAudioDataModule as W
+    real = W.iterate_shard
+
+    def counting(path):
+        for smp in real(path):
+            reads.append(smp["__key__"])
+            yield smp
+    W.iterate_shard = counting
+    try:
+        it = raw_samples(shards, random.Random(0), shuffle=50, initial=10)
+        first = next(it)
+        assert isinstance(first["flac"], bytes) and len(reads) <= 20          # two reads per sample given while the buffer grows
+        seen = {first["__key__"]}
+        for _ in range(600):
+            seen.add(next(it)["__key__"])
+        assert len(seen) == 120                                              # every clip of every shard comes through
+    finally:
+        W.iterate_shard = real
+    empty = tmp_path / "empty.tar"
+    with tarfile.open(empty, "w"):
+        pass
+    with pytest.raises(RuntimeError, match="in a row"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        next(raw_samples([str(empty)], random.Random(0), shuffle=10, initial=2, max_shard_failures=4))
+
+
 def test_dataset_functions_match_the_reference():
     """Known answers + the reference's own data_modules/dataset_functions.py outputs (fixture)."""
     from wavjepa_amd.data_modules import dataset_functions as F

@@ -5,9 +5,14 @@ Same constructor, `setup("fit")` / `train_dataloader()` and batch layout as the 
     (audio [B, 1, 10 s * sr] fp32, context_mask [B, S, T], target_indices [B, S, G, T], ctx_and_target_masks [B, S, G, T])
 
 Pipeline per worker (reference :86-121): shards drawn WITH replacement (`resampled=True`, split by rank and worker through the
-seed) -> members grouped by key -> shuffle buffer (1000) -> decode the `.flac` member (native decoder, wavjepa_amd/audio_io.py;
-undecodable members are reported and skipped, as `wds.warn_and_continue` does) -> channel 0 -> kaiser-sinc resampling to `sr` when
-the file's rate differs -> RMS -14 dBFS, pad / cut to 10 s -> masks from the masker -> batches of `batch_size`.  Several data
+seed) -> members grouped by key -> shuffle buffer (1000) of the RAW `{ext: bytes}` samples, as webdataset shuffles before
+`.decode()` / `.map()` (a compressed 10 s clip is ~0.2 MB where the decoded, resampled, masked item is 0.64 MB and costs 15 ms
+of CPU: a buffer of prepared items was ~40 GB per rank at 16 workers and delayed the first batch by 1000 decodes); it starts
+yielding once it holds SHUFFLE_INITIAL = 100 samples, webdataset's `initial` -> decode the `.flac` member (native decoder,
+wavjepa_amd/audio_io.py; the STREAMINFO MD5 is verified for the first VERIFY_MD5_CLIPS clips of every worker; undecodable
+members and any per-sample failure are reported and skipped, as `wds.warn_and_continue` does) -> channel 0 -> kaiser-sinc
+resampling to `sr` when the file's rate differs -> RMS -14 dBFS, pad / cut to 10 s -> masks from the masker -> batches of
+`batch_size`.  MAX_SHARD_FAILURES unreadable shards in a row raise instead of spinning on warnings.  Several data
 directories are mixed with `mixing_weights` (webdataset's RandomMix: a source is drawn with probability ~ its weight for every
 batch).  Workers are the torch DataLoader's processes, as upstream.
 """
@@ -72,9 +77,45 @@ def iterate_shard(path: str) -> Iterator[dict]:
             yield sample
 
 
+def raw_samples(shards: List[str], rng: random.Random, shuffle: int, initial: int = 100, max_shard_failures: int = 16) -> Iterator[dict]:
+    """Endless stream of RAW `{ext: bytes}` samples that carry a .flac member -- shards drawn with replacement -- through
+    webdataset's shuffle stage: the buffer takes two samples per sample it gives until it holds `shuffle` of them, and gives (a
+    uniformly drawn one) as soon as it holds `initial`.  `max_shard_failures` shards in a row without a readable sample raise."""
+    def stream() -> Iterator[dict]:
+        failures = 0
+        while True:
+            shard = shards[rng.randrange(len(shards))]
+            got = 0
+            try:
+                for raw in iterate_shard(shard):
+                    if "flac" in raw:
+                        got += 1
+                        yield raw
+            except (tarfile.TarError, OSError) as e:
+                warnings.warn(f"{shard}: {e!r}; shard skipped")
+            failures = 0 if got else failures + 1
+            if failures >= max_shard_failures:
+                raise RuntimeError(f"{failures} shards in a row gave no readable .flac sample (last: {shard})")
+
+    buf: List[dict] = []
+    initial = min(initial, max(shuffle, 1))
+    src = stream()
+    for raw in src:
+        buf.append(raw)
+        if len(buf) < shuffle:
+            buf.append(next(src))
+        if len(buf) >= initial:
+            j = rng.randrange(len(buf))
+            buf[j], buf[-1] = buf[-1], buf[j]
+            yield buf.pop()
+
+
 class WebAudioDataModule(_Base):
     TARGET_SECONDS: int = 10
     SHUFFLE: int = 1000
+    SHUFFLE_INITIAL: int = 100
+    VERIFY_MD5_CLIPS: int = 64
+    MAX_SHARD_FAILURES: int = 16
     NUM_WORKERS: int = 16
     PREFETCH_FACTOR: int = 2
 
@@ -108,32 +149,16 @@ class WebAudioDataModule(_Base):
         return audio, ctx, tgt, vis
 
     def _samples(self, shards: List[str], rng: random.Random, shuffle: int) -> Iterator[tuple]:
-        """Endless stream of prepared samples from `shards` (drawn with replacement), through a shuffle buffer."""
-        buf: List[tuple] = []
-        while True:
-            shard = shards[rng.randrange(len(shards))]
+        """Endless stream of prepared samples: raw samples popped from the shuffle buffer, then decoded and prepared."""
+        decoded = 0
+        for raw in raw_samples(shards, rng, shuffle, self.SHUFFLE_INITIAL, self.MAX_SHARD_FAILURES):
             try:
-                members = iterate_shard(shard)
-                for raw in members:
-                    if "flac" not in raw:
-                        continue
-                    try:
-                        item = self._retrieve_sample(audio_io.decode_flac(raw["flac"]))
-                    except Exception as e:                           # noqa: BLE001  (wds.warn_and_continue)
-                        warnings.warn(f"{shard}:{raw.get('__key__')}: {e!r}; skipped")
-                        continue
-                    if len(buf) < shuffle:
-                        buf.append(item)
-                        continue
-                    j = rng.randrange(len(buf))
-                    buf[j], item = item, buf[j]
-                    yield item
-            except (tarfile.TarError, OSError) as e:
-                warnings.warn(f"{shard}: {e!r}; shard skipped")
-            if buf and len(shards) == 1 and len(buf) < shuffle:          # a corpus smaller than the buffer: drain instead of spinning
-                rng.shuffle(buf)
-                yield from buf
-                buf = []
+                item = self._retrieve_sample(audio_io.decode_flac(raw["flac"], verify_md5=decoded < self.VERIFY_MD5_CLIPS))
+            except Exception as e:                                   # noqa: BLE001  (wds.warn_and_continue: any per-sample failure)
+                warnings.warn(f"{raw.get('__key__')}: {e!r}; skipped")
+                continue
+            decoded += 1
+            yield item
 
     def _batches(self, worker: int, n_workers: int) -> Iterator[tuple]:
         rng = random.Random(f"{self.seed}/{self.rank}/{self.world_size}/{worker}/{n_workers}")

@@ -23,7 +23,7 @@ import torch
 from .. import audio_io
 from ..resample import KAISER_BEST, resample_waveform_cpu
 from .dataset_functions import pre_process, pre_process_noise
-from .WebAudioDataModule import _Base, expand_shards, iterate_shard
+from .WebAudioDataModule import _Base, expand_shards, iterate_shard, raw_samples
 
 
 def fade_noise(noise: torch.Tensor, audio: torch.Tensor, sr: int) -> torch.Tensor:
@@ -81,6 +81,9 @@ class WebAudioDataModuleDenoiser(_Base):
     NUM_WORKERS: int = 16
     PREFETCH_FACTOR: int = 2
     SHUFFLE: int = 1000
+    SHUFFLE_INITIAL: int = 100
+    VERIFY_MD5_CLIPS: int = 64
+    MAX_SHARD_FAILURES: int = 16
 
     def __init__(self, data_dir: str, rir_dir: str, noise_dir: str, batch_size: int = 32, with_noise: bool = False, with_rir: bool = False,
                  nr_samples_per_audio: int = 16, nr_time_points: int = 100, cache_size: int = 1000, snr_low: float = -5.0, snr_high: float = 5.0,
@@ -129,39 +132,22 @@ class WebAudioDataModuleDenoiser(_Base):
         shards = expand_shards(self.data_dir)
         rir_loader = npy_stream(expand_shards(self.rir_dir), rng) if self.with_rir else None
         noise_loader = npy_stream(expand_shards(self.noise_dir), rng) if self.with_noise else None
-        buf, batch = [], []
-        while True:
-            shard = shards[rng.randrange(len(shards))]
-            progressed = False
-            for raw in iterate_shard(shard):
-                if "flac" not in raw:
-                    continue
-                try:
-                    item = self._augment_sample(audio_io.decode_flac(raw["flac"]), rir_loader, noise_loader)
-                except audio_io.AudioDecodeError as e:       # wds.warn_and_continue
-                    warnings.warn(f"{shard}:{raw.get('__key__')}: {e!r}; skipped")
-                    continue
-                progressed = True
-                if len(buf) < self.SHUFFLE:
-                    buf.append(item)
-                    if len(shards) > 1 or len(buf) < self.SHUFFLE:
-                        continue
-                j = rng.randrange(len(buf))
-                buf[j], item = item, buf[j]
-                batch.append(item)
-                if len(batch) == self.batch_size:
-                    yield collate(batch)
-                    batch = []
-            if buf and len(shards) == 1 and len(buf) < self.SHUFFLE:      # a corpus smaller than the buffer: drain it
-                rng.shuffle(buf)
-                for item in buf:
-                    batch.append(item)
-                    if len(batch) == self.batch_size:
-                        yield collate(batch)
-                        batch = []
-                buf = []
-            if not progressed and not buf:
-                raise RuntimeError(f"{shard}: no decodable .flac member")
+        # the shuffle buffer holds RAW samples (webdataset shuffles before decode / map): a prepared item is 10 s of 32 kHz fp32 audio
+        # + zero-padded noise + RIR sets, 2.6 GB per worker at 1000 items; decoding, resampling and augmenting happen on the sample
+        # popped from the buffer.  Any per-sample failure is reported and skipped (wds.warn_and_continue).
+        batch, decoded = [], 0
+        for raw in raw_samples(shards, rng, self.SHUFFLE, self.SHUFFLE_INITIAL, self.MAX_SHARD_FAILURES):
+            try:
+                item = self._augment_sample(audio_io.decode_flac(raw["flac"], verify_md5=decoded < self.VERIFY_MD5_CLIPS), rir_loader,
+                                            noise_loader)
+            except Exception as e:                           # noqa: BLE001
+                warnings.warn(f"{raw.get('__key__')}: {e!r}; skipped")
+                continue
+            decoded += 1
+            batch.append(item)
+            if len(batch) == self.batch_size:
+                yield collate(batch)
+                batch = []
 
     def setup(self, stage: str):
         if stage == "fit":
