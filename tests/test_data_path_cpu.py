@@ -172,7 +172,6 @@ def test_shuffle_buffer_holds_raw_samples_and_starts_early(tmp_path):
     """The reference shuffles the raw tar samples BEFORE decode / map (webdataset .shuffle(1000) ahead of .decode): the buffer must hold
     bytes, give its first sample after `initial` reads, grow to `shuffle`, cover the corpus, and unreadable shards must raise."""
     import random
-    from wavjepa_amd.data_modules.WebAudioDataModule import raw_samples
     shards = []
     for sh in range(3):
         path = tmp_path / f"s{sh}.tar"
@@ -184,7 +183,8 @@ def test_shuffle_buffer_holds_raw_samples_and_starts_early(tmp_path):
                 tf.addfile(info, io.BytesIO(data))
         shards.append(str(path))
     reads = []
-    import wavjepa_amd.data_modules.WebAudioDataModule as W
+    import importlib
+    W = importlib.import_module("wavjepa_amd.data_modules.WebAudioDataModule")      # the module (the package re-exports the class under this name)
     real = W.iterate_shard
 
     def counting(path):
@@ -193,6 +193,7 @@ def test_shuffle_buffer_holds_raw_samples_and_starts_early(tmp_path):
             yield smp
     W.iterate_shard = counting
     try:
+        raw_samples = W.raw_samples
         it = raw_samples(shards, random.Random(0), shuffle=50, initial=10)
         first = next(it)
         assert isinstance(first["flac"], bytes) and len(reads) <= 20          # two reads per sample given while the buffer grows
