@@ -150,3 +150,32 @@ def test_train_py_two_ranks_share_the_gpu_over_gloo(tmp_path):
     ckpts = list((tmp_path / "runs").rglob("last.ckpt"))
     assert len(ckpts) == 1 and "NrGPUs=2" in str(ckpts[0])
 
+
+
+@pytest.mark.timeout(900)
+def test_train_py_config4_nat_scenes_two_ranks_over_gloo(tmp_path):
+    """BASELINE config 4 through the launcher: `train.py extractor=wavjepa_nat data=nat_synthetic masker=AudioSet_nat` under
+    torch.distributed.run with two ranks -- binaural scenes generated on the device inside the step (source RIR + 2 noise RIRs, SNR
+    mix), one mono conv stack per ear (ConvChannelFeatureExtractor), 2 x 200 tokens per clip, channel-based masks in the extractor's
+    channel-major order, bucketed gradient averages.  The heart-beat lines of both ranks must show every start-up stage."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "train.py"), "extractor=wavjepa_nat", "data=nat_synthetic",
+           "masker=AudioSet_nat", "trainer.num_gpus=2", "trainer.steps=3", "trainer.batch_size=2", "data.samples_per_audio=2",
+           "data.source_seconds=4.0", "trainer.log_every_n_steps=1", f"save_dir={tmp_path / 'runs'}"]
+    from tests import launch
+    rc, out, err = launch.run(cmd, cwd=root, env=dict(os.environ, WJ_DIST_BACKEND="gloo"), timeout=300)
+    assert rc == 0, (out[-1500:], err[-4000:])
+    steps = [ln for ln in out.splitlines() if ln.startswith("step ")]
+    assert [ln.split()[1] for ln in steps] == ["1", "2", "3"], out[-1500:]
+    assert all(np.isfinite(float(ln.split("loss")[1].split()[0])) for ln in steps)
+    ckpts = list((tmp_path / "runs").rglob("last.ckpt"))
+    assert len(ckpts) == 1 and "Extractor=wavjepa-nat" in str(ckpts[0]) and "Data=NatSynthetic" in str(ckpts[0])
+    import torch
+    sd = torch.load(ckpts[0], map_location="cpu", weights_only=False)["state_dict"]
+    assert sd["pos_encoding_encoder"].shape[1] == 400                                   # 2 channels x 200 tokens
+    assert any(k.startswith("extract_audio.") for k in sd)
+    for r in (0, 1):
+        for stage in ("process group up", "parameters broadcast from rank 0", "first optimisation step"):
+            assert any(f"[rank {r}/2" in ln and stage in ln for ln in err.splitlines()), (r, stage, err[-3000:])

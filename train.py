@@ -16,7 +16,7 @@ import torch
 from utils import checkpoint_dir, get_identity_from_cfg
 from wavjepa_amd.config import load_config, parse_conv_spec
 from wavjepa_amd.data import SyntheticAudioSource
-from wavjepa_amd.extractors import ConvFeatureExtractor, Extractor
+from wavjepa_amd.extractors import ConvChannelFeatureExtractor, ConvFeatureExtractor, Extractor
 from wavjepa_amd.jepa import JEPA
 from wavjepa_amd.masking import SpeechMasker, TimeInverseBlockMasker
 from wavjepa_amd.trainer import Trainer
@@ -24,7 +24,9 @@ from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
 
 NETWORKS = {"JEPA": JEPA}
 MASKERS = {"time-inverse": TimeInverseBlockMasker, "speech-masker": SpeechMasker}
-EXTRACTORS = {"wav2vec2": ConvFeatureExtractor, "wavjepa": ConvFeatureExtractor}
+EXTRACTORS = {"wav2vec2": ConvFeatureExtractor, "wavjepa": ConvFeatureExtractor,
+              # BASELINE config 4 (WavJEPA-Nat): the reference's registry (train.py:26-29) never selects its channel extractor; this one does
+              "wavjepa-nat": ConvChannelFeatureExtractor}
 
 
 class ComponentFactory:
@@ -33,6 +35,9 @@ class ComponentFactory:
         cls = EXTRACTORS.get(cfg.extractor.name)
         if cls is None:
             raise ValueError(f"Unknown extractor type: {cfg.extractor.name}. Available extractors: {list(EXTRACTORS.keys())}")
+        if cls is ConvChannelFeatureExtractor:
+            return cls(conv_layers_spec=parse_conv_spec(cfg.extractor.conv_layers_spec), in_channels=cfg.data.in_channels,
+                       share_weights_over_channels=bool(cfg.extractor.get("share_weights_over_channels", False)))
         return cls(conv_layers_spec=parse_conv_spec(cfg.extractor.conv_layers_spec), in_channels=cfg.data.in_channels,
                    depthwise=cfg.extractor.depthwise)
 
@@ -52,7 +57,8 @@ class ComponentFactory:
         length = mk.get("context_length", mk.get("context_mask_length"))
         return TimeInverseBlockMasker(target_masks_per_context=mk.target_masks_per_context, context_mask_prob=prob,
                                       context_mask_length=length, target_prob=mk.target_prob, target_length=mk.target_length,
-                                      ratio_cutoff=mk.ratio_cutoff, channel_based_masking=mk.channel_based_masking)
+                                      ratio_cutoff=mk.ratio_cutoff, channel_based_masking=mk.channel_based_masking,
+                                      channel_major=bool(mk.get("channel_major", False)))
 
     @staticmethod
     def create_network(cfg, extractor: Extractor) -> JEPA:
@@ -89,6 +95,13 @@ def build_model(cfg):
 
 def create_data_source(cfg, nr_patches, device, rank):
     masker = ComponentFactory.create_masker(cfg)
+    if cfg.data.name == "NatSynthetic":     # BASELINE config 4: binaural scenes generated on the device inside the step
+        from wavjepa_amd.data import NatSceneSource
+        if int(cfg.data.in_channels) != 2:
+            raise ValueError("data=nat_synthetic produces 2-channel scenes: data.in_channels must be 2")
+        return NatSceneSource(masker, batch_size=cfg.trainer.batch_size, samples_per_audio=cfg.data.samples_per_audio, n_tokens=nr_patches,
+                              sr=cfg.data.sr, seconds=cfg.data.get("source_seconds", 10.0), rir_seconds=cfg.data.get("rir_seconds", 0.5),
+                              n_noise=int(cfg.data.get("n_noise", 2)), seed=cfg.seed + rank, device=device)
     if cfg.data.name != "Synthetic":        # tar shards of .flac clips (reference train.py:94-110 -> data_modules/WebAudioDataModule.py)
         from wavjepa_amd.data_modules import WebAudioDataModule
         dm = WebAudioDataModule(masker, data_dirs=cfg.data.data_dirs, mixing_weights=cfg.data.get("mixing_weights", None),
