@@ -329,6 +329,28 @@ def test_denoiser_oracle_matches_reference_fixture(golden_dir):
         assert shp == tuple(fx[f"sd::{k}"].shape), k
 
 
+def test_resample_tap_tables_match_the_pinned_closed_form(golden_dir):
+    """tests/golden/resample_kernel.npz (make_resample_kernel.py): torchaudio's closed-form tap tables evaluated with exact rational tap
+    times and scipy's Bessel function, for the reference's parameters.  The oracle's float64 table and the PRODUCT's float32 table
+    (wavjepa_amd.resample.sinc_resample_kernel: what the GPU kernel and the loader workers convolve with) must equal them."""
+    from oracle import resample_oracle as R
+    from wavjepa_amd.resample import KAISER_BEST, sinc_resample_kernel
+    fx = np.load(os.path.join(golden_dir, "resample_kernel.npz"))
+    for key in fx.files:
+        o, n, m = key.split("_")
+        o, n = int(o), int(n)
+        want = fx[key]
+        if m == "kaiser":
+            ko, width, orig, new = R.kernel(o, n, KAISER_BEST["lowpass_filter_width"], KAISER_BEST["rolloff"], "sinc_interp_kaiser", KAISER_BEST["beta"])
+            kp, wp, op, npp = sinc_resample_kernel(o, n, resampling_method="sinc_interp_kaiser", **KAISER_BEST)
+        else:
+            ko, width, orig, new = R.kernel(o, n)
+            kp, wp, op, npp = sinc_resample_kernel(o, n)
+        assert ko.shape == want.shape == kp.shape and (width, orig, new) == (wp, op, npp), key
+        assert np.abs(ko - want).max() < 1e-13, (key, np.abs(ko - want).max())
+        assert kp.dtype == np.float32 and np.array_equal(kp, want.astype(np.float32)), key     # the product table is the float32 rounding
+
+
 def test_resample_oracle_known_answers():
     """oracle/resample_oracle.py (torchaudio's published kaiser-sinc resampling, restated): properties that follow from the
     definition at the reference's call site (32 kHz -> 16 kHz, width 64, rolloff 0.9476, beta 14.77), and the host-side kernel
