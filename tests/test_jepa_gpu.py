@@ -1,6 +1,6 @@
 """End-to-end parity of the HIP path (wavjepa_amd.JEPA through the C ABI) against the oracle on the same seeded
 inputs (GPU only).  Tolerances: loss within 1e-3 relative of the oracle's bf16 mode (the north-star criterion);
-bf16 activations within 1e-2 relative L2; mask gather bit-exact; parameter gradients within 3e-2 relative L2 per
+bf16 activations within 1.25 x the stock-autocast distance (ACT_TOL); mask gather bit-exact; parameter gradients within 1e-2 (BASE) / 1.5e-2 relative L2 per
 tensor group (two independent bf16 pipelines)."""
 import os
 
@@ -75,6 +75,16 @@ def group_of(name):
     return "other"
 
 
+# Tolerances (relative L2), anchored on the yardstick test below: PyTorch's own bf16 autocast sits 0.61 / 0.69 / 0.65 % from the fp32
+# truth on local / contextual features / targets of the BASE model (profiles/r03_parity_report.log); two independent bf16 pipelines
+# (HIP path vs the oracle's bf16 flow) measure 0.65-0.69 % on BASE and 0.69-0.87 % on the small model.  Bounds = 1.25 x those
+# distances; gradient groups: <= 1e-2 on BASE (measured <= 0.48 %), <= 1.5e-2 on the small models (<= 0.74 %).  A regression that
+# doubles any error fails.
+ACT_TOL = {"base": dict(local_features=8.6e-3, targets=8.6e-3, contextual_features=8.6e-3, preds=7.0e-3),
+           "small": dict(local_features=9.2e-3, targets=9.6e-3, contextual_features=1.08e-2, preds=7.5e-3)}
+GRAD_TOL = {"base": 1.0e-2, "small": 1.5e-2}
+
+
 @pytest.mark.parametrize("cfg_name,n,ragged", [("small", 4, True), ("small", 4, False), ("small", 1, True), ("small", 1, False),
                                                 ("base", 2, True), ("base", 2, False)])      # n = 1: a single clip (fewer rows than one GEMM tile)
 def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
@@ -103,13 +113,13 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
         assert float(out["preds"][~seen].float().abs().max()) == 0.0
     else:
         report["preds_all"] = rel(out["preds"].float(), ref["preds"].float())
-        assert report["preds_all"] < 2e-2
+        assert report["preds_all"] < ACT_TOL[cfg_name]["preds"]
     lo, lr_, l32 = float(out["loss"]), float(ref["loss"]), float(ref32["loss"])
     print(cfg_name, "rel errors vs oracle bf16:", report, "loss hip/oracle-bf16/oracle-fp32:", lo, lr_, l32)
     assert out["local_features"].dtype == torch.float32 and out["preds"].dtype == torch.bfloat16
     assert out["contextual_features"].shape == ref["contextual_features"].shape
-    assert report["local_features"] < 1e-2 and report["targets"] < 1e-2
-    assert report["contextual_features"] < 2e-2 and report["preds"] < 2e-2
+    for k, bound in ACT_TOL[cfg_name].items():
+        assert report[k] < bound, (k, report[k], bound)
     assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)          # north-star: loss within 1e-3 rel of the bf16 reference flow
     assert abs(lo - l32) < 2e-2 * abs(l32)
     # backward
@@ -125,7 +135,7 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
     print(cfg_name, "grad rel errors per group:", errs)
     for g, e in errs.items():
-        assert e < 3e-2, (g, e)
+        assert e < GRAD_TOL[cfg_name], (g, e)
 
 
 def test_batch_size_changes_between_steps(golden_dir):
@@ -174,7 +184,7 @@ def test_stock_pytorch_autocast_yardstick_base_model(golden_dir):
     print("stock-autocast yardstick (rel L2):", rep, "loss hip / stock autocast / fp32:", lh, ls, l32)
     for k, r in rep.items():
         assert r["hip_vs_fp32"] < 1.25 * r["stock_autocast_vs_fp32"] + 1e-4, (k, r)
-        assert r["hip_vs_stock_autocast"] < 1.5 * r["stock_autocast_vs_fp32"] + 1e-4, (k, r)
+        assert r["hip_vs_stock_autocast"] < 1.25 * r["stock_autocast_vs_fp32"] + 1e-4, (k, r)
     assert abs(lh - ls) < 1e-3 * abs(ls), (lh, ls)
 
 
@@ -204,7 +214,7 @@ def test_forward_backward_parity_speech_masks(golden_dir):
     errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
     print("speech masks: loss", lo, lr_, "grad rel errors per group:", errs)
     for g, e in errs.items():
-        assert e < 3e-2, (g, e)
+        assert e < GRAD_TOL["small"], (g, e)
 
 
 @pytest.mark.parametrize("ragged", [True, False])
@@ -225,7 +235,7 @@ def test_forward_backward_parity_400_tokens(golden_dir, ragged):
     ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(SMALL))
     lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
     assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
-    assert rel(out["targets"].float(), ref["targets"].float()) < 1e-2
+    assert rel(out["targets"].float(), ref["targets"].float()) < ACT_TOL["small"]["targets"]
     out["loss"].backward()
     ref["loss"].backward()
     got = dict(m.named_parameters())
@@ -238,7 +248,7 @@ def test_forward_backward_parity_400_tokens(golden_dir, ragged):
     errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
     print("400 tokens, ragged" if ragged else "400 tokens, dense", "loss", lo, lr_, "grad rel errors per group:", errs)
     for g, e in errs.items():
-        assert e < 3e-2, (g, e)
+        assert e < GRAD_TOL["small"], (g, e)
 
 
 def test_forward_backward_parity_seven_layer_wav2vec2_spec(golden_dir):
@@ -259,7 +269,7 @@ def test_forward_backward_parity_seven_layer_wav2vec2_spec(golden_dir):
     ref = J.jepa_forward(P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), mode="bf16", **oracle_kw(cfg))
     lo, lr_ = float(out["loss"].detach()), float(ref["loss"].detach())
     assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)
-    assert rel(out["local_features"].float(), ref["local_features"].float()) < 1e-2
+    assert rel(out["local_features"].float(), ref["local_features"].float()) < 1e-2        # seven bf16 conv layers deep
     assert rel(out["targets"].float(), ref["targets"].float()) < 1e-2
     out["loss"].backward()
     ref["loss"].backward()
@@ -273,7 +283,7 @@ def test_forward_backward_parity_seven_layer_wav2vec2_spec(golden_dir):
     errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
     print("seven-layer spec: loss", lo, lr_, "grad rel errors per group:", errs)
     for g, e in errs.items():
-        assert e < 3e-2, (g, e)
+        assert e < GRAD_TOL["small"], (g, e)                     # measured 0.39-0.74 %
 
 
 def test_forward_backward_parity_two_channel_audio(golden_dir):
@@ -294,7 +304,7 @@ def test_forward_backward_parity_two_channel_audio(golden_dir):
     got = dict(m.named_parameters())
     for k in ("extract_audio.cnn.0.0.weight", "extract_audio.cnn.0.2.weight", "extract_audio.cnn.1.0.weight"):
         e = rel(got[k].grad.float(), P[k].grad.float())
-        assert e < 3e-2, (k, e)
+        assert e < 2e-2, (k, e)                                  # single tensors of the conv stack (not a group)
 
 
 @pytest.mark.parametrize("G", [2, 6])
@@ -325,7 +335,7 @@ def test_forward_backward_parity_other_group_counts(golden_dir, G):
         num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
         den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
     for g in num:
-        assert (num[g] / max(den[g], 1e-300)) ** 0.5 < 3e-2, (G, g)
+        assert (num[g] / max(den[g], 1e-300)) ** 0.5 < GRAD_TOL["small"], (G, g)
     out4 = m(audio, ctx, tgt, vis)
     assert m._engine.G == 4 and out4["preds"].shape[0] == 12
     with pytest.raises(ValueError):
@@ -365,7 +375,7 @@ def test_data_parallel_gradient_semantics_two_micro_batches(golden_dir):
         num[g] = num.get(g, 0.0) + float((got - want).pow(2).sum())
         den[g] = den.get(g, 0.0) + float(want.pow(2).sum())
     for g in num:
-        assert (num[g] / max(den[g], 1e-300)) ** 0.5 < 3e-2, (g, (num[g] / den[g]) ** 0.5)
+        assert (num[g] / max(den[g], 1e-300)) ** 0.5 < GRAD_TOL["small"], (g, (num[g] / den[g]) ** 0.5)
 
 
 def test_full_size_batch_256_clips_equals_its_slices():
@@ -479,7 +489,8 @@ def test_forward_backward_parity_channel_extractor(stacks, ragged):
     print(stacks, "ragged" if ragged else "dense", "loss", lo, lr_, "grad rel errors per group:", errs)
     assert sum(1 for g in errs if g.startswith("extract_audio.cnns")) == (2 if stacks == "own" else 1)
     for g, e in errs.items():
-        assert e < 3e-2, (g, e)
+        # a per-channel conv stack sees half of the tokens of a clip: its gradient is the noisiest group (measured 0.9-1.6 %)
+        assert e < (2.5e-2 if g.startswith("extract_audio.cnns") else GRAD_TOL["small"]), (g, e)
     # the stand-alone extractor forward gives the same tokens as the oracle's front-end
     tok = m.extract_audio(audio)
     want = J.conv_frontend({k: v.detach() for k, v in P.items()}, audio, SMALL_SPEC, "bf16")
