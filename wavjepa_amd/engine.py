@@ -417,16 +417,40 @@ class JepaEngine:
             out.append(a)
         return out
 
-    def alloc(self, N: int, train: bool = True, G: int = 0) -> None:
-        """(Re)build the arena for N clips (and, for training, G target groups per clip)."""
+    def alloc(self, N: int, train: bool = True, G: int = 0, need_enc: int = 0, need_dec: int = 0) -> None:
+        """(Re)build the arena for N clips (and, for training, G target groups per clip).
+
+        need_enc / need_dec: rows the student / predictor buffers must hold this step (a ragged step: its context / visible rows;
+        a dense step: N*T / N*G*T; 0 = dense).  The student / predictor activations, their backward scratch and the prediction
+        buffers are sized for that need + WJ_ARENA_MARGIN (default 15 %), not for the dense worst case: with the AudioSet masker a
+        ragged step touches 19 % / 42 % of the dense rows, and those buffers were 57 of the 86 GB of a 256-clip arena.  A later step
+        that needs more (a batch with more visible tokens, the dense fall-back, WJ_RAGGED=0) grows them -- a re-allocation, rare by
+        construction.  WJ_ARENA_DENSE=1 sizes everything for the dense step up front."""
+        import os
         G = G or self.G or 1
-        if N == self.N and (not train or (getattr(self, "_train_alloc", False) and G == self.G)):
+        full_enc, full_dec = N * self.T, N * G * self.T
+        if os.environ.get("WJ_ARENA_DENSE", "0") == "1" or not train:
+            need_enc, need_dec = full_enc, full_dec
+        need_enc = min(need_enc or full_enc, full_enc)
+        need_dec = min(need_dec or full_dec, full_dec)
+        same = N == self.N and (not train or (getattr(self, "_train_alloc", False) and G == self.G))
+        if same and (not train or (need_enc <= self.cap_enc and need_dec <= self.cap_dec)):
             return
+        margin = float(os.environ.get("WJ_ARENA_MARGIN", "1.15"))
+
+        def cap(need: int, full: int, old: int) -> int:
+            if need >= full:
+                return full
+            return min(full, max((int(need * margin) + 255) // 256 * 256, old if same else 0))
+
+        self.cap_enc = cap(need_enc, full_enc, getattr(self, "cap_enc", 0))
+        self.cap_dec = cap(need_dec, full_dec, getattr(self, "cap_dec", 0))
         c, bf, f32, dev = self.cfg, torch.bfloat16, torch.float32, self.dev
         T, C = self.T, self.C
         M, Mp = N * T, N * G * T
         self.N, self.G, self.M, self.Mp = N, G, M, Mp
         self._train_alloc = train
+        Me, Md = self.cap_enc, self.cap_dec                   # rows of the student / predictor buffers (<= M / Mp)
         nl = len(c.conv_spec)
         Nc = N * self.S                               # mono conv clips (channel-major: clip index c*N + n)
         # conv activations (post-GELU, and pre-GELU for layers >= 1) + their gradients
@@ -459,7 +483,7 @@ class JepaEngine:
         self.lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         # fp8 mode: one activation scratch (e4m3 bytes + block scales) per stack (the teacher runs beside the student)
         self._a8, self._a8s = {}, {}
-        for tag, (m, d) in dict(tea=(M, c.d_enc), enc=(M, c.d_enc), dec=(Mp if train else 0, c.d_dec)).items():
+        for tag, (m, d) in dict(tea=(M, c.d_enc), enc=(Me if train else M, c.d_enc), dec=(Md if train else 0, c.d_dec)).items():
             if m > 0:
                 self._a8[tag] = (_empty(m, 4 * d, dtype=torch.uint8, device=dev),
                                  torch.zeros(ops.fp8_scale_dwords(m, 4 * d), dtype=torch.int32, device=dev))
@@ -473,21 +497,21 @@ class JepaEngine:
         self.enc_fr = _empty(M, dtype=f32, device=dev)
         if not train:
             return
-        self.enc_acts = self._alloc_stack(M, c.d_enc, c.h_enc, N, c.l_enc)
-        self.dec_acts = self._alloc_stack(Mp, c.d_dec, c.h_dec, N * G, c.l_dec)
-        self.ctx_in = _empty(M, c.d_enc, dtype=bf, device=dev)       # gathered context rows (<= M)
-        self.enc_in = _empty(M, c.d_enc, dtype=f32, device=dev)      # ragged: local features of the context rows
-        self.enc_in_b = _empty(M, c.d_enc, dtype=bf, device=dev)
-        self.tail_o = _empty(Mp, c.d_dec, dtype=bf, device=dev)      # last predictor layer: target rows of o / x_in / do
-        self.tail_x = _empty(Mp, c.d_dec, dtype=f32, device=dev)
-        self.tail_do = _empty(Mp, c.d_dec, dtype=bf, device=dev)
-        self.cf = _empty(M, c.d_dec, dtype=bf, device=dev)           # contextual_features
-        self.dec_in = _empty(Mp, c.d_dec, dtype=f32, device=dev)
-        self.dec_in_b = _empty(Mp, c.d_dec, dtype=bf, device=dev)
-        self.dec_out_b = _empty(Mp, c.d_dec, dtype=bf, device=dev)
-        self.dec_fm = _empty(Mp, dtype=f32, device=dev)
-        self.dec_fr = _empty(Mp, dtype=f32, device=dev)
-        self.preds = _empty(Mp, c.d_enc, dtype=bf, device=dev)
+        self.enc_acts = self._alloc_stack(Me, c.d_enc, c.h_enc, N, c.l_enc)
+        self.dec_acts = self._alloc_stack(Md, c.d_dec, c.h_dec, N * G, c.l_dec)
+        self.ctx_in = _empty(Me, c.d_enc, dtype=bf, device=dev)      # gathered context rows (<= Me)
+        self.enc_in = _empty(Me, c.d_enc, dtype=f32, device=dev)     # ragged: local features of the context rows
+        self.enc_in_b = _empty(Me, c.d_enc, dtype=bf, device=dev)
+        self.tail_o = _empty(Md, c.d_dec, dtype=bf, device=dev)      # last predictor layer: target rows of o / x_in / do
+        self.tail_x = _empty(Md, c.d_dec, dtype=f32, device=dev)
+        self.tail_do = _empty(Md, c.d_dec, dtype=bf, device=dev)
+        self.cf = _empty(Me, c.d_dec, dtype=bf, device=dev)          # contextual_features
+        self.dec_in = _empty(Md, c.d_dec, dtype=f32, device=dev)
+        self.dec_in_b = _empty(Md, c.d_dec, dtype=bf, device=dev)
+        self.dec_out_b = _empty(Md, c.d_dec, dtype=bf, device=dev)
+        self.dec_fm = _empty(Md, dtype=f32, device=dev)
+        self.dec_fr = _empty(Md, dtype=f32, device=dev)
+        self.preds = _empty(Md, c.d_enc, dtype=bf, device=dev)
         self.targets = _empty(M, c.d_enc, dtype=f32, device=dev)
         # teacher: outputs of the last top_k layers (fp32) and their per-clip (sum, sum of squares)
         nkeep = min(c.top_k, c.l_enc) if 1 < c.top_k <= 8 else 0
@@ -497,7 +521,7 @@ class JepaEngine:
         self.mse_ws = _empty(ops.workspace_bytes("wj_masked_mse", B=N, G=G, T=T) // 4, dtype=f32, device=dev)
         # backward scratch, one set per stack width
         self.bw = {}
-        for tag, (m, d, nbuf, group) in dict(enc=(M, c.d_enc, 4, 2), dec=(Mp, c.d_dec, 2, 1)).items():
+        for tag, (m, d, nbuf, group) in dict(enc=(Me, c.d_enc, 4, 2), dec=(Md, c.d_dec, 2, 1)).items():
             # The weight gradients of `group` consecutive layers go out as ONE grouped launch on the side stream (wj_wgrad_grouped:
             # one small split-K factor for 4-8 problems instead of a large one per problem).  The buffers it reads (dY of every
             # linear) therefore exist 2 * group times (slot = layer % nbuf), so that the main chain may run a whole group ahead.
@@ -515,9 +539,9 @@ class JepaEngine:
                         ops.workspace_bytes("wj_attn_bwd", B=N * G, H=c.h_dec, hd=c.d_dec // c.h_dec),
                         ops.workspace_bytes("wj_attn_bwd", B=N, H=c.h_enc, hd=c.d_enc // c.h_enc))
         self.red_ws = _empty(red_bytes // 4, dtype=f32, device=dev)
-        self.dpreds = _empty(Mp, c.d_enc, dtype=bf, device=dev)
-        self.d_cf = _empty(M, c.d_dec, dtype=bf, device=dev)
-        self.d_ctx_in = _empty(M, c.d_enc, dtype=bf, device=dev)
+        self.dpreds = _empty(Md, c.d_enc, dtype=bf, device=dev)
+        self.d_cf = _empty(Me, c.d_dec, dtype=bf, device=dev)
+        self.d_ctx_in = _empty(Me, c.d_enc, dtype=bf, device=dev)
         self.d_lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         self.d_fn = _empty(M, C, dtype=f32, device=dev)
 
@@ -716,7 +740,8 @@ class JepaEngine:
         N = audio.shape[0]
         if plan.N != N or plan.T != self.T or plan.G < 1:
             raise ValueError(f"mask plan is for {plan.N} clips x {plan.G} groups x {plan.T} tokens; the batch has {N} clips of {self.T} tokens")
-        self.alloc(N, train=True, G=plan.G)
+        rag = self.ragged and plan.ragged_ok
+        self.alloc(N, train=True, G=plan.G, need_enc=plan.n_ctx if rag else 0, need_dec=plan.n_dec if rag else 0)
         self.plan = plan
         self.audio = audio
         M, Mp, T, G = self.M, self.Mp, self.T, self.G
