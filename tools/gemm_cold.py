@@ -24,12 +24,11 @@ for (M, N, K, epi) in SHAPES:
     if C2 is not None:
         kw["C2"] = C2
     out = []
-    for v in variants:
-        ops.gemm_set_variant(v)
-        res = {}
+    ts = {(v, mode): [] for v in variants for mode in ("warm", "cold")}
+    for r in range(12):                      # the variants interleaved, so that a clock drift hits all of them alike
         for mode in ("warm", "cold"):
-            ts = []
-            for r in range(8):
+            for v in variants:
+                ops.gemm_set_variant(v)
                 if mode == "cold":
                     junk.fill_(float(r))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,8 +37,9 @@ for (M, N, K, epi) in SHAPES:
                 e1.record()
                 torch.cuda.synchronize()
                 if r > 1:
-                    ts.append(e0.elapsed_time(e1) * 1e3)
-            res[mode] = sorted(ts)[len(ts) // 2]
+                    ts[(v, mode)].append(e0.elapsed_time(e1) * 1e3)
+    for v in variants:
+        res = {mode: sorted(ts[(v, mode)])[len(ts[(v, mode)]) // 2] for mode in ("warm", "cold")}
         out.append(f"variant {v}: warm {res['warm']:7.1f} us, cold {res['cold']:7.1f} us")
     print(f"M={M} N={N} K={K} epi={epi}: " + " | ".join(out))
 ops.gemm_set_variant(-1)
