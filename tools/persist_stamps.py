@@ -35,11 +35,14 @@ for (M, Nn, K, epi) in SHAPES:
         ops.gemm(A, W, C, **kw)
     torch.cuda.synchronize()
     # poison, then ONE launch
-    buf = np.zeros(256 * N, dtype=np.uint64)
+    buf = np.zeros(2 * 256 * N, dtype=np.uint64)
     ops.gemm(A, W, C, **kw)
-    rc = lib.wj_debug_persist_stamps(buf.ctypes.data, 256 * N)
+    rc = lib.wj_debug_persist_stamps(buf.ctypes.data, 2 * 256 * N)
     assert rc == 0
-    s = buf.reshape(256, N).astype(np.int64)
+    ph = buf[256 * N:].reshape(256, N).astype(np.int64)[:, :56].reshape(256, 7, 8)    # tiles 0-6: end of each phase of K tiles 0, 1
+    s = buf[:256 * N].reshape(256, N).astype(np.int64)
+    act = int(os.environ.get("WJ_PERSIST_ACTIVE", "32"))                    # diagnostic: only the first `act` workgroups of every XCD work
+    work = np.nonzero((np.arange(256) >> 3) < act)[0]
     clk = s[:, N - 2:].copy()
     s[:, N - 2:] = 0
     t0 = s[:, 0].min()
@@ -51,9 +54,14 @@ for (M, Nn, K, epi) in SHAPES:
     epi_t = (det[:, 1:5, 2] - det[:, 1:5, 1]) / 100.0
     last_rt = np.array([s[w, :N - 2][s[w, :N - 2] > 0].max() for w in range(256)])
     ghz = (clk[:, 1] - clk[:, 0]) / np.maximum(1, (last_rt - s[:, 1])) / 10.0
+    ghz, pair, rest, epi_t = ghz[work], pair[work], rest[work], epi_t[work]
     print(f"   shader clock between the prologue and the last stamp: median {np.median(ghz):.3f} GHz (min {ghz.min():.3f}, max {ghz.max():.3f})")
     print(f"   tiles 1-4 (median over WGs): first K-tile pair {np.median(pair):.2f} us, rest of K loop {np.median(rest):.2f} us "
           f"({np.median(rest) / max(1, K // 64 - 2):.3f} us/K-tile), epilogue issue {np.median(epi_t):.2f} us")
+    # phases of the first K-tile pair, tiles 1-4: time from the end of the previous epilogue to the end of phase 0 of K tile 0, then
+    # phase by phase
+    ph_d = np.diff(np.concatenate([prev_end[:, 1:5, None], ph[:, 1:5, :]], axis=2), axis=2) / 100.0
+    print("   first K-tile pair phase by phase (us, median): " + " ".join(f"{v:.2f}" for v in np.median(ph_d[work].reshape(-1, 8), axis=0)))
     s = np.concatenate([s[:, :2], s[:, 4::3]], axis=1)                      # keep [start, prologue, tile ends] for the summary below
     ntile = np.array([int(((s[w, 2:] > s[w, 1]) & (s[w, 2:] - t0 < 10_000_000)).sum()) for w in range(256)])
     start = (s[:, 0] - t0) / 100.0

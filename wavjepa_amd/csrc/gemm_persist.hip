@@ -39,14 +39,16 @@ constexpr int NT = 512;
 constexpr unsigned BUF = 65536u, BOFF = 32768u;   // LDS: two parities of [A 256 rows | B 256 rows] x 128 B
 constexpr unsigned AUX = 131072u;                 // [2 tiles][8 waves][64 floats] bias of the wave's 64 columns
 constexpr unsigned MAILBOX = AUX + 4096u;         // next-next tile index, written by wave 0
-constexpr int LDS_TOTAL = (int)MAILBOX + 64;
+constexpr unsigned STAGE = MAILBOX + 256u;          // [8 waves][16 rows x STAGE_ROW B]: the epilogue's transpose (per wave, no barriers)
+constexpr unsigned STAGE_ROW = 144u;               // 128 B of bf16 + 16: the 8-byte writes of a 32-lane pass and the 16-byte reads of a row hit distinct banks
+constexpr int LDS_TOTAL = (int)(STAGE + 8u * 16u * STAGE_ROW);
 constexpr int SLOTS = 64;                         // counter sets (one per stream that launches this kernel)
 constexpr int CTR_STRIDE = 32;                    // dwords between the 8 counters of a set (one 128-B line each)
 
 __device__ unsigned g_sched_ctr[SLOTS * 8 * CTR_STRIDE];
 __device__ __attribute__((aligned(256))) unsigned char g_zero_bias[256];
 constexpr int STAMP_N = 64;
-__device__ unsigned long long g_stamps[256 * STAMP_N];   // diagnostic (WJ_PERSIST_STAMPS=1): start, end of prologue, end of every tile
+__device__ unsigned long long g_stamps[2 * 256 * STAMP_N];   // diagnostic (WJ_PERSIST_STAMPS=1): start, end of prologue, end of every tile
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -62,6 +64,7 @@ struct PArgs {
     unsigned lda_b, ldb_b;    // bytes
     int M, N, K, tiles_n, ntiles;
     int seg_rows, seg_valid;
+    int active;                   // diagnostic (with stamps): only the first `active` workgroups of every XCD work (32 = all)
     unsigned long long* stamps;   // diagnostic: [256 workgroups][STAMP_N] s_memrealtime values (100 MHz), or NULL
 };
 
@@ -109,7 +112,7 @@ template <int PAR, int LAG, bool FIRST>
 __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s, const char* nA, const char* nB, unsigned y_skip,
                                         unsigned b1_skip, const unsigned (&vx)[2], const unsigned (&vb)[2], const unsigned (&dx)[2],
                                         const unsigned (&db)[2], unsigned a_lo, unsigned b_lo, bool last1, bool last2, bool has_next,
-                                        bool lag, bool mail, const unsigned& pv, const f32x4 (&bv)[4]) {
+                                        bool lag, bool mail, const unsigned& pv, const f32x4 (&bv)[4], unsigned long long* st = nullptr) {
     constexpr unsigned CUR = PAR * BUF, OTH = (PAR ^ 1) * BUF;
     char* cur = smem + CUR;
     const unsigned a_hi = a_lo ^ 64u, b_hi = b_lo ^ 64u;
@@ -145,13 +148,6 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     } else {
         wait_vmcnt<0>();
     }
-    if constexpr (PAR == 1 && FIRST) {
-        if (mail) {
-            // the pull issued before this output tile's first K tile is older than the pieces the wait above retired: pv has landed
-            asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tds_write_b32 %1, %0\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
-                         ::"v"(pv), "v"(MAILBOX) : "memory");
-        }
-    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -165,6 +161,7 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if constexpr (FIRST) { if (st && threadIdx.x == 0) st[PAR * 4 + 0] = __builtin_amdgcn_s_memrealtime(); }
     // ---- phase 1: B1 of this tile; stage B1(t+1)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -189,6 +186,7 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if constexpr (FIRST) { if (st && threadIdx.x == 0) st[PAR * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
     // ---- phase 2: Y of this tile; stage B0(t+2) into THIS parity
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -213,6 +211,7 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if constexpr (FIRST) { if (st && threadIdx.x == 0) st[PAR * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
     // ---- phase 3: no fragment reads; stage X(t+2) into THIS parity; wait for X(t+1), B0(t+1)
     __builtin_amdgcn_sched_barrier(0);
     if (more2) {
@@ -237,6 +236,16 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     } else {
         wait_vmcnt<0>();
     }
+    if constexpr (PAR == 1 && FIRST) {
+        if (mail) {
+            // The pull went out before this output tile's first K tile; every wait of this phase leaves at most the 8 pieces staged
+            // since then in flight, so pv has landed.  (Phase 0's wait does NOT guarantee that: behind an epilogue it tolerates LAG
+            // more operations, and in wave 0 the pull is one of them -- with a fast epilogue the stale register reached the mailbox
+            // about once in 40 launches, and a tile was computed twice while another was skipped.)
+            asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tds_write_b32 %1, %0\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                         ::"v"(pv), "v"(MAILBOX) : "memory");
+        }
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -250,6 +259,7 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if constexpr (FIRST) { if (st && threadIdx.x == 0) st[PAR * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -259,28 +269,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, p);
 }
 
-// lane rows g and g^1 trade halves: afterwards (x0, x1, y0, y1) are 8 consecutive columns of one output row
-__device__ __forceinline__ u32x4 widen(unsigned x0, unsigned x1, unsigned y0, unsigned y1) {
-    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-    return u32x4{s0[0], s1[0], s0[1], s1[1]};
-}
-
 // Number of global stores one wave issues per output tile
 template <int EPI> struct StoreCount { static constexpr int N = (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU) ? 16 : 32; };
-
-// Lanes i and i ^ 8 of a 16-lane row trade quarters: in: w0 / w1 = this lane's 8 columns of the left / right 32-column half of its
-// row i; out: s0 = 8 columns of row (i & 7), s1 = 8 columns of row 8 + (i & 7), both in half (i >> 3).  A wave-instruction that
-// stores s0 (or s1) then writes 8 rows x 128 B -- whole cache lines.  (With the half-line form, 16 rows x 64 B per instruction,
-// the vector memory path spends its time per LINE touched: the epilogue took 4.2 us per tile instead of ~2, and the L2 had to
-// fetch every line it was handed half of.)
-__device__ __forceinline__ void fullrow(const u32x4& w0, const u32x4& w1, u32x4& s0, u32x4& s1) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        s0[d] = __builtin_amdgcn_update_dpp(w0[d], w1[d], 0x128 /* row_ror:8 */, 0xF, 0xC, false);   // lanes 8-15 <- w1 of lane i - 8
-        s1[d] = __builtin_amdgcn_update_dpp(w1[d], w0[d], 0x128, 0xF, 0x3, false);                  // lanes 0-7  <- w0 of lane i + 8
-    }
-}
 
 // 16-byte non-temporal global store: the C tile is not re-read by this kernel, and kept out of the L2's way its operand panels
 // stay resident (measured with tools/persist_stamps.py: 1.30 instead of 1.37 us per K tile on the teacher's QKV shape, and
@@ -289,22 +279,36 @@ __device__ __forceinline__ void store16(char* p, const u32x4& v) {
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 }
 
-// accumulators (bias included: it was the C operand of their first MFMA) -> bf16 (-> GELU) -> 16-byte stores.
+// accumulators (bias included: it was the C operand of their first MFMA) -> bf16 (-> GELU) -> transposed through LDS -> 16-byte stores.
 // acc[mi][ni][r] = C[m0 + wm*128 + mi*16 + i][n0 + wn*64 + ni*16 + 4 g + r]   (i = lane & 15, g = lane >> 4)
-template <int EPI, bool FULLROW>
-__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], const PArgs& a, int m0, int n0, int wm, int wn, int lane) {
+// In that layout consecutive lanes hold different ROWS, and a wave store whose consecutive lanes touch different cache lines is handled
+// line by line: 2.3 us per 128-KB tile and CU however the lanes are permuted inside the wave, against 0.6 us when every 8 consecutive
+// lanes write one whole 128-B line (tools/micro/store_path.hip).  So each 16-row block takes one trip through a per-wave LDS strip:
+// four 8-byte writes in the MFMA layout, two 16-byte reads with lane -> (row lane >> 3, 16-B chunk lane & 7), two stores of 8 rows x
+// 128 B.  One wave's LDS operations execute in order, so the strip needs neither waits nor barriers between its uses.
+template <int EPI>
+__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, const PArgs& a, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
     const int ln = opaque(lane);
     const int i = ln & 15, g = ln >> 4;
-    // FULLROW (after widen() + fullrow()): this lane stores rows (i & 7) and 8 + (i & 7) of each 16-row block, columns
-    // wn*64 + (i >> 3)*32 + (g & 1)*16 + (g >> 1)*8 .. + 7; otherwise (after widen()): row i, those columns of both 32-column halves
-    const long lane_off = FULLROW ? (long)(i & 7) * a.ldc_b + (long)(wn * 64 + (i >> 3) * 32 + (g & 1) * 16 + (g >> 1) * 8) * 2
-                                  : (long)i * a.ldc_b + (long)(wn * 64 + (g & 1) * 16 + (g >> 1) * 8) * 2;
+    char* strip = smem + STAGE + wave * (16 * STAGE_ROW);
+    char* wr = strip + i * STAGE_ROW + g * 8;                                  // + ni * 32
+    const char* rd = strip + (ln >> 3) * STAGE_ROW + (ln & 7) * 16;            // + 8 * STAGE_ROW for rows 8-15
+    const long lane_off = (long)(ln >> 3) * a.ldc_b + (long)(wn * 128 + (ln & 7) * 16);
     char* c1 = a.C + ((long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2) + lane_off;
     char* c2 = nullptr;
     if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) c2 = a.C2 + ((long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2) + lane_off;
     int rem = 0;                                       // CONV_GELU: row % seg_rows, carried from row to row + 16 (seg_rows > 16)
     if constexpr (EPI == WJ_EPI_CONV_GELU) rem = (m0 + wm * 128 + i) % a.seg_rows;
     const long row8 = 8 * a.ldc_b;
+    auto through_strip = [&](const u32x2 (&o)[4], char* dst) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<u32x2*>(wr + ni * 32) = o[ni];
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(rd);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(rd + 8 * STAGE_ROW);
+        store16(dst, lo);
+        store16(dst + row8, hi);
+    };
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         bool valid = true;
@@ -313,66 +317,48 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], const PArgs& a
             rem += 16;
             rem = rem >= a.seg_rows ? rem - a.seg_rows : rem;
         }
-        u32x4 w1[2], w2[2];                             // [column half]: first output (C), second output (C2)
+        u32x2 o1[4], o2[4];                             // [ni]: 4 columns of the first output (C), of the second output (C2)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const f32x4 va = acc[mi][2 * p], vb = acc[mi][2 * p + 1];
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni];
             if constexpr (EPI == WJ_EPI_BF16) {
-                w1[p] = widen(pack_bf16(va[0], va[1]), pack_bf16(va[2], va[3]), pack_bf16(vb[0], vb[1]), pack_bf16(vb[2], vb[3]));
+                o1[ni] = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
             } else {
                 // h = bf16(acc + bias), as a bf16 linear returns it; gelu / gelu' of THAT value (nn.GELU on a bf16 tensor)
-                f32x2 h[4], gl[4], gp[4];
-                h[0] = f32x2{bf2f(f2bf(va[0])), bf2f(f2bf(va[1]))};
-                h[1] = f32x2{bf2f(f2bf(va[2])), bf2f(f2bf(va[3]))};
-                h[2] = f32x2{bf2f(f2bf(vb[0])), bf2f(f2bf(vb[1]))};
-                h[3] = f32x2{bf2f(f2bf(vb[2])), bf2f(f2bf(vb[3]))};
+                f32x2 h[2], gl[2], gp[2];
+                h[0] = f32x2{bf2f(f2bf(v[0])), bf2f(f2bf(v[1]))};
+                h[1] = f32x2{bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     if constexpr (EPI == WJ_EPI_BIAS_GELU2) gelu_pk<true>(h[q], gl[q], gp[q]);
                     else gelu_pk<false>(h[q], gl[q], gp[q]);
                 }
                 if constexpr (EPI == WJ_EPI_CONV_GELU) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 2; ++q) {
                         h[q].x = valid ? h[q].x : 0.f; h[q].y = valid ? h[q].y : 0.f;
                         gl[q].x = valid ? gl[q].x : 0.f; gl[q].y = valid ? gl[q].y : 0.f;
                     }
                 }
-                const u32x4 og = widen(pack_bf16(gl[0].x, gl[0].y), pack_bf16(gl[1].x, gl[1].y), pack_bf16(gl[2].x, gl[2].y), pack_bf16(gl[3].x, gl[3].y));
+                const u32x2 og = u32x2{pack_bf16(gl[0].x, gl[0].y), pack_bf16(gl[1].x, gl[1].y)};
                 if constexpr (EPI == WJ_EPI_BIAS_GELU) {
-                    w1[p] = og;
+                    o1[ni] = og;
                 } else if constexpr (EPI == WJ_EPI_BIAS_GELU2) {
-                    w1[p] = widen(pack_bf16(gp[0].x, gp[0].y), pack_bf16(gp[1].x, gp[1].y), pack_bf16(gp[2].x, gp[2].y), pack_bf16(gp[3].x, gp[3].y));   // C  = gelu'(h)
-                    w2[p] = og;                                                                                                                     // C2 = gelu(h)
+                    o1[ni] = u32x2{pack_bf16(gp[0].x, gp[0].y), pack_bf16(gp[1].x, gp[1].y)};   // C  = gelu'(h)
+                    o2[ni] = og;                                                                   // C2 = gelu(h)
                 } else {   // CONV_GELU: C = pre, C2 = post
-                    w1[p] = widen(pack_bf16(h[0].x, h[0].y), pack_bf16(h[1].x, h[1].y), pack_bf16(h[2].x, h[2].y), pack_bf16(h[3].x, h[3].y));
-                    w2[p] = og;
+                    o1[ni] = u32x2{pack_bf16(h[0].x, h[0].y), pack_bf16(h[1].x, h[1].y)};
+                    o2[ni] = og;
                 }
             }
         }
         const long off = (long)(mi * 16) * a.ldc_b;
-        if constexpr (FULLROW) {
-            u32x4 s0, s1;
-            fullrow(w1[0], w1[1], s0, s1);
-            store16(c1 + off, s0);
-            store16(c1 + off + row8, s1);
-            if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) {
-                fullrow(w2[0], w2[1], s0, s1);
-                store16(c2 + off, s0);
-                store16(c2 + off + row8, s1);
-            }
-        } else {
-            store16(c1 + off, w1[0]);
-            store16(c1 + off + 64, w1[1]);
-            if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) {
-                store16(c2 + off, w2[0]);
-                store16(c2 + off + 64, w2[1]);
-            }
-        }
+        through_strip(o1, c1 + off);
+        if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) through_strip(o2, c2 + off);
     }
 }
 
-template <int EPI, bool FULLROW>
+template <int EPI>
 __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     constexpr int LAG = StoreCount<EPI>::N + 1;       // + the bias DMA of the block that precedes an output tile's first K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -443,6 +429,8 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 
     f32x4 acc[8][4];                                   // defined by the first K tile of every output tile (C = 0 there)
 
+    if (a.stamps && (int)(blockIdx.x >> 3) >= a.active) return;   // diagnostic: a partly idle chip (WJ_PERSIST_ACTIVE)
+
     // ---- prologue: first tile is static; pull the second
     int m0, n0;
     tile_coords(blockIdx.x >> 3, m0, n0);
@@ -484,6 +472,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 
     bool lag = false;
     int slot = 0;
+    int tile_iter = 0;                                // diagnostic (phase stamps)
     for (;;) {
         // ---- before the first K tile of an output tile: where the next one starts, its bias, and the pull for the one after
         int m1 = m0, n1 = n0;
@@ -506,10 +495,12 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 64 + g * 16);
         }
+        unsigned long long* st = (a.stamps && tile_iter < 7) ? a.stamps + 256 * STAMP_N + blockIdx.x * STAMP_N + tile_iter * 8 : nullptr;
+        ++tile_iter;
         pp_tile<0, LAG, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, 2 == n, has_next, lag, false, pv,
-                              bv);
+                              bv, st);
         pp_tile<1, LAG, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, 2 == n, false, has_next, lag,
-                              pulled && wave == 0, pv, bv);
+                              pulled && wave == 0, pv, bv, st);
         stamp();                                       // diagnostic: end of the first two K tiles
         for (int kt = 2; kt < n; kt += 2) {
             pp_tile<0, LAG, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, kt + 2 == n, has_next, false,
@@ -527,16 +518,21 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
         // ---- epilogue from the registers
         __builtin_amdgcn_sched_barrier(0);
         stamp();                                       // diagnostic: end of the K loop
+        // Waves 4-7 run one barrier behind: left alone, waves 0-3 would run their epilogue while 4-7 wait at a barrier, and 4-7 theirs
+        // while 0-3 wait at the next one -- two epilogues back to back (measured: 2.0 + 3.0 us per tile).  One extra barrier for waves
+        // 0-3 here and one for waves 4-7 behind the epilogue keep the lag and put both epilogues side by side.
+        if (wm == 0) __builtin_amdgcn_s_barrier();
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA results of the last phase -> VALU readers behind the loop branch
-        epilogue_regs<EPI, FULLROW>(acc, a, m0, n0, wm, wn, lane);
+        epilogue_regs<EPI>(acc, smem, a, m0, n0, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (wm == 1) __builtin_amdgcn_s_barrier();
         stamp();
         if (!has_next) break;
         lag = true;                                    // every tile issues all of its stores (edge tiles are shifted, not clipped)
         m0 = m1; n0 = n1;
         slot ^= 1;
         if (pulled) {
-            // the word wave 0 wrote in the second K tile of the tile just finished (>= 6 barriers ago for either wave group; the next
+            // the word wave 0 wrote in the second K tile of the tile just finished (>= 2 barriers ago for either wave group; the next
             // write is a K tile away)
             unsigned mv = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
             mv = __builtin_amdgcn_readfirstlane(mv);
@@ -573,17 +569,20 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr) {
         static int stamps = -1;                     // WJ_PERSIST_STAMPS=1: diagnostic time stamps (tools/persist_stamps.py)
         if (stamps < 0) { const char* v = getenv("WJ_PERSIST_STAMPS"); stamps = v ? atoi(v) : 0; }
         p.stamps = nullptr;
+        p.active = 32;
         if (stamps) {
+            const char* av = getenv("WJ_PERSIST_ACTIVE");
+            if (av) p.active = atoi(av);
             void* sp = nullptr;
             if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_stamps)) == hipSuccess) p.stamps = (unsigned long long*)sp;
         }
     }
-    // (measured: whole-line stores are worth 1-3 % on the teacher's shapes and 7 % on 8192^3 over 16 rows x 64 B per instruction)
-    auto kern = gemm_persist_kernel<EPI, true>;
+    auto kern = gemm_persist_kernel<EPI>;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // once per kernel
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(256), dim3(NT), LDS_TOTAL, s, p);
     WJ_CHECK_LAUNCH();
+    if (p.active < 32) (void)hipMemsetAsync(ctr, 0, 8 * CTR_STRIDE * sizeof(unsigned), s);   // diagnostic: idle workgroups made no pulls, the counters did not wrap
     return WJ_OK;
 }
 
@@ -605,7 +604,7 @@ bool wj_gemm_persist_eligible(const wj_gemm_args* a) {
 // diagnostic: copy the stamp buffer to the host (synchronises the device)
 extern "C" int wj_debug_persist_stamps(unsigned long long* out, int n) {
     if (!out || n <= 0) return WJ_ERR_ARG;
-    if (n > 256 * STAMP_N) n = 256 * STAMP_N;
+    if (n > 2 * 256 * STAMP_N) n = 2 * 256 * STAMP_N;       // second half: per-phase stamps of the first K-tile pair of tiles 0-6
     if (hipDeviceSynchronize() != hipSuccess) return WJ_ERR_LAUNCH;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8) != hipSuccess) return WJ_ERR_LAUNCH;
     return WJ_OK;
