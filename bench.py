@@ -96,7 +96,8 @@ def pmc_traffic_for(name: str):
         return None
     epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5}[m.group(3)]
     prefix = f"gemm3_kernel<{'true' if m.group(1) == 'T' else 'false'}, {'true' if m.group(2) == 'T' else 'false'}, {epi},"
-    persist = f"gemm_persist_kernel<{6 if m.group(3) == 'BIAS_GELU' else epi},"       # the persistent variant of the forward shapes
+    pn = 6 if m.group(3) == "BIAS_GELU" else epi                                      # the persistent variant of the forward shapes
+    persist = (f"gemm_persist_kernel<{pn}>", f"gemm_persist_kernel<{pn},")
     with open(path) as fh:
         kernels = json.load(fh)["kernels"]
     hits = [v for k, v in kernels.items() if k.startswith(prefix) or (m.group(1) == "N" and m.group(2) == "N" and k.startswith(persist))]

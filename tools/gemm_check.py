@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 bf = torch.bfloat16
 SHAPES = [  # M, N, K, epilogue
     (51200, 2304, 768, ops.EPI_BF16), (51200, 768, 768, ops.EPI_BF16), (51200, 768, 3072, ops.EPI_BF16),
-    (51200, 3072, 768, ops.EPI_BIAS_GELU), (9907, 2304, 768, ops.EPI_BF16), (9907, 768, 3072, ops.EPI_BF16),
+    (51200, 3072, 768, ops.EPI_BIAS_GELU), (9907, 2304, 768, ops.EPI_BF16), (9907, 768, 3072, ops.EPI_BF16), (9907, 768, 768, ops.EPI_BF16),
     (9907, 3072, 768, ops.EPI_BIAS_GELU2), (86317, 1536, 384, ops.EPI_BIAS_GELU2), (86317, 1152, 384, ops.EPI_BF16),
     (86317, 384, 1536, ops.EPI_BF16), (86317, 384, 384, ops.EPI_BF16), (8192, 8192, 8192, ops.EPI_BF16),
     (300, 256, 128, ops.EPI_BF16), (257, 512, 256, ops.EPI_BF16), (1000, 264, 384, ops.EPI_BF16),
