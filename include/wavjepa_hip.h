@@ -118,10 +118,18 @@ typedef struct {
 } wj_wgrad_group_args;
 int wj_wgrad_grouped(const wj_wgrad_group_args*, void* stream);
 
-/* Tuning / A-B hook (tools/gemm_bench.py, tests): force the tile/schedule variant of wj_gemm_bf16 (0..3, see csrc/gemm.hip;
- * a variant that cannot run a shape falls back to variant 0); -1 = automatic selection.  Returns the previous setting.
- * Same effect as the WJ_GEMM_VARIANT environment variable.  Results do not depend on the variant beyond fp32 summation order. */
+/* Tuning / A-B hook (tools/gemm_check.py, tests): force the tile/schedule variant of wj_gemm_bf16 (0..4, see csrc/gemm.hip; 4 = the
+ * persistent eight-phase kernel of csrc/gemm_persist.hip; a variant that cannot run a shape falls back to 3, then 0); -1 = automatic
+ * selection.  Returns the previous setting.  Same effect as the WJ_GEMM_VARIANT environment variable.  Variants 0-3 give bit-identical
+ * outputs (same k order, bias added last); variant 4 starts its accumulators from the bias: a last-place difference of the bf16 output
+ * on <= 0.05 % of the elements. */
 int wj_gemm_set_variant(int variant);
+
+/* Diagnostic (tools/persist_stamps.py; only filled when the process runs with WJ_PERSIST_STAMPS=1): copies the time stamps the last
+ * persistent-GEMM launch wrote -- [2][256 workgroups][64] s_memrealtime values (100 MHz): start, end of prologue, per output tile the
+ * end of its first K-tile pair / K loop / epilogue; second half: the eight phases of that first pair -- to `out` (n 64-bit words).
+ * Synchronises the device.  Not part of the drop-in surface. */
+int wj_debug_persist_stamps(unsigned long long* out, int n);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LayerNorm (fp32 statistics), optionally fused with the post-norm residual add.

@@ -224,7 +224,15 @@ def test_denoiser_training_steps_reduce_the_loss():
     assert changed == len(before)
     mine = {id(p) for p in den.parameters()}
     assert not any(id(p) in mine for p in den.teacher.parameters())          # the teacher is outside parameters() / the optimiser
-    assert not any(k.startswith("teacher") for k in den.state_dict())
+    # ... but in the state_dict, under the reference's names (its Denoiser holds the teacher as a sub-module): strict interchange
+    sd = den.state_dict()
+    tsd = den.teacher.state_dict()
+    assert {k for k in sd if k.startswith("teacher.")} == {"teacher." + k for k in tsd}
+    assert all(torch.equal(sd["teacher." + k], v) for k, v in tsd.items())
+    poisoned = {k: (torch.full_like(v, 0.5) if k == "teacher.feature_norms.weight" else v) for k, v in sd.items()}
+    den.load_state_dict(poisoned)                                             # strict: every key known, teacher entries routed
+    assert float(den.teacher.feature_norms.weight.mean()) == 0.5
+    den.load_state_dict({k: v for k, v in sd.items() if not k.startswith("teacher.")})   # a student-only dict still strict-loads
 
 
 def test_denoise_py_runs_end_to_end(tmp_path):

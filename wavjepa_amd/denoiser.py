@@ -160,8 +160,8 @@ class Denoiser(_ModuleBase):
                          transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384), resample_sr=self.sr, size="base",
                          process_audio_seconds=self.process_audio_seconds)
             model.load_state_dict(sd, strict=False)
-        # Frozen by construction: the teacher is NOT a sub-module (its weights are in neither parameters() / the optimiser nor this
-        # state_dict) and only its inference entry is ever called.  (The reference also flips requires_grad off, denoiser.py:177-178;
+        # Frozen by construction: the teacher is NOT a sub-module (its weights are in neither parameters() nor the optimiser; its
+        # state_dict entries are added by hand under `teacher.*`, as the reference's checkpoints have them) and only its inference entry is ever called.  (The reference also flips requires_grad off, denoiser.py:177-178;
         # here that flag selects what lives in the flat parameter buffer the kernels read, so it stays as it is.)
         model.eval()
         object.__setattr__(self, "teacher", model)
@@ -183,8 +183,23 @@ class Denoiser(_ModuleBase):
             self.teacher._apply(fn, *a, **k)
         return out
 
+    def state_dict(self, *args, destination=None, prefix: str = "", keep_vars: bool = False):
+        """The reference's Denoiser holds its frozen teacher as a sub-module (denoiser.py:146-181), so its Lightning checkpoints carry
+        `teacher.*` entries.  Here the teacher is deliberately NOT a sub-module (it must stay out of parameters(), the optimiser and
+        the flat buffer), so its entries are added under the same names: a checkpoint written here strict-loads in the reference."""
+        out = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if self.teacher is not None:
+            self.teacher.state_dict(destination=out, prefix=prefix + "teacher.", keep_vars=keep_vars)
+        return out
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        """`teacher.*` entries (a reference Denoiser checkpoint, or one written here) are routed to the frozen teacher when there is
+        one and dropped otherwise (`_set_teacher` builds it from its own checkpoint); everything else loads as usual."""
+        own = {k: v for k, v in state_dict.items() if not k.startswith("teacher.")}
+        tea = {k[len("teacher."):].replace("._orig_mod", ""): v for k, v in state_dict.items() if k.startswith("teacher.")}
+        out = super().load_state_dict(own, strict=strict, **kw)
+        if tea and self.teacher is not None:
+            self.teacher.load_state_dict(tea, strict=strict)
         self._student_bf16_fresh = False
         return out
 
