@@ -24,6 +24,8 @@ SHAPES = [  # M, N, K, epilogue
     # >= 256 output tiles with ragged edges (the persistent variant's pull / edge paths), short K, conv epilogue
     (65537, 264, 128, ops.EPI_BF16), (33000, 520, 256, ops.EPI_BIAS_GELU2), (70001, 384, 1536, ops.EPI_BF16),
     (102912, 512, 1536, ops.EPI_CONV_GELU), (51456, 512, 1024, ops.EPI_CONV_GELU),
+    # N % 256 == 128 (last tile column = a half item), N % 256 in (128, 256) (shifted edge tile), a split tail with GELU2 outputs
+    (40000, 640, 256, ops.EPI_BIAS_GELU2), (40000, 448, 384, ops.EPI_BF16), (16640, 1024, 256, ops.EPI_BIAS_GELU2), (19000, 1152, 128, ops.EPI_BIAS_GELU),
 ]
 ref_v, new_v = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 3
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6

@@ -12,7 +12,8 @@ from wavjepa_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
 SHAPES = [(51200, 2304, 768, ops.EPI_BF16), (51200, 768, 3072, ops.EPI_BF16), (51200, 768, 768, ops.EPI_BF16),
-          (51200, 3072, 768, ops.EPI_BIAS_GELU), (86317, 1536, 384, ops.EPI_BIAS_GELU2), (86317, 1152, 384, ops.EPI_BF16)]
+          (51200, 3072, 768, ops.EPI_BIAS_GELU), (86317, 1536, 384, ops.EPI_BIAS_GELU2), (86317, 1152, 384, ops.EPI_BF16),
+          (86317, 384, 1536, ops.EPI_BF16), (86317, 384, 384, ops.EPI_BF16)]
 variants = [int(v) for v in sys.argv[1:]] or [3, 4]
 junk = torch.empty(768 * 1024 * 1024 // 4, device=dev)
 for (M, N, K, epi) in SHAPES:

@@ -27,6 +27,7 @@
 //     the last one resets it: no memset between launches, no host-side state besides a stream -> counter-slot table.
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include "common.h"
@@ -304,8 +305,13 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, co
     auto through_strip = [&](const u32x2 (&o)[4], char* dst) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<u32x2*>(wr + ni * 32) = o[ni];
+        // No instruction; keeps the compiler from moving the strip's writes / reads across these points.  The lanes exchange data
+        // through the strip without a barrier hipcc knows of: with a branch around the stores (tried for half-width tiles) it sank the
+        // second output's strip WRITES into the branch -- in one thread's view their only reader -- and the lanes outside never wrote.
+        __builtin_amdgcn_wave_barrier();
         const u32x4 lo = *reinterpret_cast<const u32x4*>(rd);
         const u32x4 hi = *reinterpret_cast<const u32x4*>(rd + 8 * STAGE_ROW);
+        __builtin_amdgcn_wave_barrier();
         store16(dst, lo);
         store16(dst + row8, hi);
     };
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 struct SlotTable {
     std::mutex mu;
     std::unordered_map<hipStream_t, int> slots;
-    unsigned* base = nullptr;
+    unsigned* base[32] = {};      // per device: g_sched_ctr is a __device__ symbol, every device has its own copy
 };
 SlotTable& table() {
     static SlotTable t;
@@ -555,7 +561,7 @@ SlotTable& table() {
 }
 
 template <int EPI>
-int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr) {
+int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev) {
     PArgs p;
     p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C; p.C2 = (char*)a->C2; p.bias = (const float*)a->bias;
     p.ctr = ctr;
@@ -578,8 +584,11 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr) {
         }
     }
     auto kern = gemm_persist_kernel<EPI>;
-    static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // once per kernel
-    if (attr != hipSuccess) return WJ_ERR_LAUNCH;
+    static std::atomic<bool> lds_ok[32];            // once per kernel and device
+    if (!lds_ok[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) return WJ_ERR_LAUNCH;
+        lds_ok[dev].store(true, std::memory_order_release);
+    }
     hipLaunchKernelGGL(kern, dim3(256), dim3(NT), LDS_TOTAL, s, p);
     WJ_CHECK_LAUNCH();
     if (p.active < 32) (void)hipMemsetAsync(ctr, 0, 8 * CTR_STRIDE * sizeof(unsigned), s);   // diagnostic: idle workgroups made no pulls, the counters did not wrap
@@ -613,13 +622,15 @@ extern "C" int wj_debug_persist_stamps(unsigned long long* out, int n) {
 int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
     if (!wj_gemm_persist_eligible(a)) return WJ_ERR_UNSUPPORTED;
     SlotTable& T = table();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return WJ_ERR_UNSUPPORTED;
     int slot;
     {
         std::lock_guard<std::mutex> lk(T.mu);
-        if (!T.base) {
+        if (!T.base[dev]) {
             void* p = nullptr;
             if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_ctr)) != hipSuccess) { (void)hipGetLastError(); return WJ_ERR_UNSUPPORTED; }
-            T.base = (unsigned*)p;
+            T.base[dev] = (unsigned*)p;
         }
         auto it = T.slots.find(s);
         if (it == T.slots.end()) {
@@ -628,12 +639,12 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
         }
         slot = it->second;
     }
-    unsigned* ctr = T.base + (size_t)slot * 8 * CTR_STRIDE;
+    unsigned* ctr = T.base[dev] + (size_t)slot * 8 * CTR_STRIDE;
     switch (a->epilogue) {
-        case WJ_EPI_BF16: return launch_persist<WJ_EPI_BF16>(a, s, ctr);
-        case WJ_EPI_BIAS_GELU2: return launch_persist<WJ_EPI_BIAS_GELU2>(a, s, ctr);
-        case WJ_EPI_BIAS_GELU: return launch_persist<WJ_EPI_BIAS_GELU>(a, s, ctr);
-        case WJ_EPI_CONV_GELU: return launch_persist<WJ_EPI_CONV_GELU>(a, s, ctr);
+        case WJ_EPI_BF16: return launch_persist<WJ_EPI_BF16>(a, s, ctr, dev);
+        case WJ_EPI_BIAS_GELU2: return launch_persist<WJ_EPI_BIAS_GELU2>(a, s, ctr, dev);
+        case WJ_EPI_BIAS_GELU: return launch_persist<WJ_EPI_BIAS_GELU>(a, s, ctr, dev);
+        case WJ_EPI_CONV_GELU: return launch_persist<WJ_EPI_CONV_GELU>(a, s, ctr, dev);
         default: return WJ_ERR_UNSUPPORTED;
     }
 }
