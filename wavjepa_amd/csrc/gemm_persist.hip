@@ -12,11 +12,13 @@
 //     swizzled chunk) is a per-lane CONSTANT of the whole kernel and sbase = matrix + tile origin + k is a wave-uniform SGPR pair
 //     advanced by the scalar unit.  The K loop carries 4 address VGPRs instead of 16 and spends no VALU instruction on addresses
 //     (while the SIMD partner runs its MFMA cluster the loading wave gets one vector-issue slot per MFMA);
-//   * the epilogue works from the accumulator registers: bias, bf16 rounding, v_permlane16_swap between lane rows g and g^1 so that
-//     every lane holds 8 consecutive columns, one 16-byte store per lane (a wave-instruction writes 16 rows x 64 B).  No LDS, no
-//     barrier: each wave stores its own 128 x 64 block while its SIMD partner (one barrier ahead or behind) multiplies;
-//   * the stores are not waited for: the first K tile after an epilogue counts them into its vmcnt thresholds (they are YOUNGER than
-//     the pieces that wait retires), and by the second K tile they have drained;
+//   * the epilogue works from the accumulator registers (the bias was the C operand of each accumulator's first MFMA): bf16 rounding
+//     (-> GELU), then every 16-row block takes one trip through a PER-WAVE strip of LDS that turns the MFMA layout (a lane = a row)
+//     into the store layout (8 consecutive lanes = one whole 128-B line of a row): the store path prices a wave store per cache line
+//     touched (tools/micro/store_path.hip: 0.6 against 2.3 us per tile and CU).  No barrier: one wave's LDS operations execute in
+//     order.  Both wave groups run their epilogues side by side (one extra barrier on each side keeps the loop's one-barrier lag);
+//   * the stores are not waited for: the first two K tiles after an epilogue count them into their vmcnt thresholds (they are YOUNGER
+//     than the pieces those waits retire); by the end of the second K tile they have drained;
 //   * edge tiles are SHIFTED, not clipped: the last tile row / column starts at M - 256 / N - 256 and recomputes a strip its
 //     neighbour also writes (same operands, same k order: the same bits).  No clamped rows, no predicated stores, every tile issues
 //     the same instruction stream -- which is what lets the vmcnt arithmetic above count on the stores;
