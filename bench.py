@@ -116,6 +116,13 @@ def profile_one_step(runner, source, step_idx: int):
         runner.step(source.next_batch(), step_idx)
         torch.cuda.synchronize()
         recs = ops.PROFILE
+        # what the bracket itself costs: the same two events around a one-wave kernel that returns at once
+        ops.PROFILE = []
+        for _ in range(64):
+            ops.spin(0)
+        torch.cuda.synchronize()
+        empty = sorted(e0.elapsed_time(e1) for _, _, e0, e1 in ops.PROFILE)
+        profile_one_step.bracket_us = round(empty[len(empty) // 2] * 1e3, 2)
     finally:
         ops.PROFILE = None
         eng.use_side = side
@@ -423,6 +430,9 @@ def main():
                             f"profiles/{os.path.basename(pmc_traffic_path())} (rocprofv3 --pmc passes of this command, committed; not collected by this run)",
                             launches_per_step=c["launches"],
                             avg_launch_ms=round(c["ms"] / c["launches"], 4),
+                            # a launch is timed between two HIP events on its stream (created without the system-scope fence); the
+                            # same bracket around a kernel that returns at once measures this much, which `achieved` does NOT subtract
+                            event_bracket_us=getattr(profile_one_step, "bracket_us", None),
                             gflop_per_launch=round(c["flops"] / c["launches"] / 1e9, 2),
                             algorithmic_bytes_per_launch=int(c["bytes"] / c["launches"]),   # operands once + outputs (+ addends)
                             all_gemm_achieved=round(all_fl / (all_ms * 1e-3) / 1e12, 1),

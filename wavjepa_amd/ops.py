@@ -42,6 +42,47 @@ def _stream() -> int:
 PROFILE = None
 
 
+class TimingEvent:
+    """A HIP event for TIMING ONLY, created with hipEventDisableSystemFence: a default event performs a system-scope fence when it
+    is recorded -- an L2 write-back / invalidate between every two kernels it brackets, which production launches do not have and
+    which both costs time inside the bracket and hands the next kernel cold caches (hip_runtime_api.h recommends the flag for exactly
+    this use).  torch.cuda.Event cannot pass the flag, so the runtime torch already loaded is called directly."""
+    _hip = None
+    DISABLE_SYSTEM_FENCE = 0x20000000
+
+    def __init__(self):
+        import ctypes
+        if TimingEvent._hip is None:
+            import os
+            TimingEvent._hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        self._ev = ctypes.c_void_p()
+        rc = TimingEvent._hip.hipEventCreateWithFlags(ctypes.byref(self._ev), ctypes.c_uint(TimingEvent.DISABLE_SYSTEM_FENCE))
+        if rc != 0:
+            raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+
+    def record(self, stream: int) -> None:
+        import ctypes
+        rc = TimingEvent._hip.hipEventRecord(self._ev, ctypes.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord failed ({rc})")
+
+    def elapsed_time(self, end: "TimingEvent") -> float:
+        """milliseconds from this event to `end` (both recorded and complete: synchronise the device first)"""
+        import ctypes
+        ms = ctypes.c_float()
+        rc = TimingEvent._hip.hipEventElapsedTime(ctypes.byref(ms), self._ev, end._ev)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._ev:
+                TimingEvent._hip.hipEventDestroy(self._ev)
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def _run(fn: str, struct_name: str, stream: Optional[int], **fields) -> None:
     a = STRUCTS[struct_name]()
     for k, v in fields.items():
@@ -49,10 +90,10 @@ def _run(fn: str, struct_name: str, stream: Optional[int], **fields) -> None:
     if PROFILE is None:
         _abi.call(fn, a, _stream() if stream is None else stream)
         return
-    s = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s = _stream() if stream is None else stream
+    e0, e1 = TimingEvent(), TimingEvent()
     e0.record(s)
-    _abi.call(fn, a, s.cuda_stream)
+    _abi.call(fn, a, s)
     e1.record(s)
     PROFILE.append((fn, fields, e0, e1))
 
@@ -116,10 +157,10 @@ def wgrad_grouped(problems, stream: Optional[int] = None) -> None:
     if PROFILE is None:
         _abi.call("wj_wgrad_grouped", a, _stream() if stream is None else stream)
         return
-    s = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s = _stream() if stream is None else stream
+    e0, e1 = TimingEvent(), TimingEvent()
     e0.record(s)
-    _abi.call("wj_wgrad_grouped", a, s.cuda_stream)
+    _abi.call("wj_wgrad_grouped", a, s)
     e1.record(s)
     PROFILE.append(("wj_wgrad_grouped", dict(flops=sum(2.0 * p[3] * p[4] * p[5] for p in problems), n=len(problems),
                                              bytes=sum(2.0 * p[5] * (p[3] + p[4]) + 4.0 * p[3] * p[4] for p in problems)), e0, e1))
