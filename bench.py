@@ -321,13 +321,24 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_begin:.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    def optional(what, fn):
-        """Legs after the timed region: never lose the JSON line over them."""
+    coll = {"broken": False}
+
+    def optional(what, fn, collective=False):
+        """Legs after the timed region: never lose the JSON line over them.  A leg that contains collectives (`collective`) and
+        fails on this rank leaves the other ranks inside a collective this rank will never join; issuing FURTHER collectives from
+        here would pair them with the wrong ones.  So after such a failure this rank issues no more collectives at all (the legs
+        below are skipped, the process group is not torn down collectively); the other ranks leave theirs through the process-group
+        timeout (WJ_DIST_TIMEOUT_S) and then do the same."""
+        if collective and coll["broken"]:
+            print(f"[bench rank {rank}] optional leg '{what}' skipped: an earlier collective leg failed on this rank", file=sys.stderr, flush=True)
+            return None
         try:
             return fn()
         except BaseException as e:                      # noqa: BLE001  (SystemExit of a check included: reported, not fatal)
             if isinstance(e, KeyboardInterrupt):
                 raise
+            if collective and dist.is_initialized() and world > 1:
+                coll["broken"] = True
             print(f"[bench rank {rank}] optional leg '{what}' failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             return None
 
@@ -381,9 +392,11 @@ def main():
             model._engine.ragged = True
 
     dense_ms = None
-    if args.dense_steps > 0 and model._engine.ragged:
+    # one GPU only: the dense-shape rate is a property of the kernels, not of the scaling run, and every extra leg with collectives
+    # in an N-rank run is one more way to lose ranks after the metric has been measured
+    if args.dense_steps > 0 and model._engine.ragged and world == 1:
         note("dense-shape block")
-        dense_ms = optional("dense-shape block", dense_block)
+        dense_ms = optional("dense-shape block", dense_block, collective=True)
         if dense_ms is not None:
             note(f"dense-shape block done: {dense_ms:.1f} ms/step")
     # data-parallel self-check: after the same number of identical optimiser steps every rank must hold the same parameters
@@ -399,7 +412,7 @@ def main():
 
     if dist.is_initialized():
         note("replica check")
-        gathered = optional("replica check", replica_check)
+        gathered = optional("replica check", replica_check, collective=True)
         if gathered is not None:
             replicas_equal = all(torch.equal(gathered[0], g) for g in gathered)
             if not replicas_equal:
@@ -490,7 +503,7 @@ def main():
                 json.dump({k: dict(ms=round(v["ms"], 3), launches=v["launches"], us_per_launch=round(v["ms"] / v["launches"] * 1e3, 1),
                                    tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in shapes}, fh, indent=1)
     if dist.is_initialized():
-        optional("final barrier", lambda: (dist.barrier(), dist.destroy_process_group()))
+        optional("final barrier", lambda: (dist.barrier(), dist.destroy_process_group()), collective=True)
     if diverged:
         raise SystemExit(diverged)          # after the line: the record exists, the exit code says the run is invalid
 

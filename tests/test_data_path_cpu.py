@@ -330,6 +330,19 @@ def test_web_audio_data_module_end_to_end(tmp_path):
     assert float(audio.abs().max()) == 0.0
     with pytest.raises(FileNotFoundError):
         DM(masker, str(tmp_path / "nothing-*.tar"), None).setup("fit")
+    # a corpus whose shards are readable but in which no clip decodes: the stream raises after MAX_SAMPLE_FAILURES consecutive
+    # failures instead of warning for ever while the trainer waits for its first batch
+    (tmp_path / "c").mkdir()
+    make_shard(tmp_path / "c" / "shard-000.tar", [(f"bad{i}", {"flac": clips_a[0][1]["flac"][:200 + i]}) for i in range(5)])
+
+    class Strict(DM):
+        MAX_SAMPLE_FAILURES = 12
+
+    bad = Strict(masker, str(tmp_path / "c"), None, batch_size=2, nr_samples_per_audio=2, nr_time_points=200, seed=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="12 samples in a row"):
+            next(bad._batches(0, 1))
 
 
 def test_denoiser_data_module_batches(tmp_path):

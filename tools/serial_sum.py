@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Kernel-time sum per training step from a `rocprofv3 --kernel-trace --stats` summary (`*_kernel_stats.csv`).
+
+The accept criterion for kernel changes (round 4): the run is made with WJ_SIDE_STREAM=0, so every kernel has the chip to itself and
+the sum of kernel durations is reproducible to ~0.1 ms per step -- the two-stream step time moves by +-0.3 ms from lease to lease and
+hides 1 % wins.  Steps are counted from the AdamW launches (one per step).
+
+  python tools/serial_sum.py <kernel_stats.csv> [<other.csv>]      # second file: per-class delta (other - first)
+"""
+from __future__ import annotations
+
+import csv
+import re
+import sys
+
+CLASSES = [   # (label, regex on the kernel name); first match wins
+    ("gemm NN persist BF16", r"gemm_persist_kernel<0[,>]"),
+    ("gemm NN persist BIAS_GELU2", r"gemm_persist_kernel<1[,>]"),
+    ("gemm NN persist BIAS_GELU", r"gemm_persist_kernel<6[,>]"),
+    ("gemm NN persist CONV_GELU", r"gemm_persist_kernel<5[,>]"),
+    ("gemm NN persist MUL_GELU_GRAD", r"gemm_persist_kernel<2[,>]"),
+    ("gemm NN persist ADD_F32", r"gemm_persist_kernel<3[,>]"),
+    ("gemm grouped wgrad", r"gemm3_grouped_wgrad_kernel"),
+    ("gemm NT (col-form B) BF16", r"gemm3_kernel<false, true, 0,"),
+    ("gemm NT MUL_GELU_GRAD", r"gemm3_kernel<false, true, 2,"),
+    ("gemm NT ADD_F32", r"gemm3_kernel<false, true, 3,"),
+    ("gemm NN one-tile BF16", r"gemm3_kernel<false, false, 0,"),
+    ("gemm NN one-tile other", r"gemm3_kernel<false, false,"),
+    ("gemm TT wgrad (ungrouped)", r"gemm3_kernel<true, true,"),
+    ("gemm other", r"gemm3_kernel|gemm_persist_kernel"),
+    ("layernorm fwd", r"ln_fwd_kernel"),
+    ("layernorm bwd", r"ln_bwd_kernel|ln_fold"),
+    ("attention fwd", r"attn_fwd"),
+    ("attention bwd", r"attn_bwd"),
+    ("conv0", r"conv0_"),
+    ("adamw / ema / sumsq / cast", r"adamw_kernel|ema_kernel|sumsq|cast_kernel"),
+    ("transpose (W^T shadows)", r"transpose"),
+    ("colsum", r"colsum"),
+    ("targets / loss", r"instnorm|mse_"),
+    ("token plumbing", r"gather_rows|scatter_fill|unmask_rows|zero_rows|add_pos|crop_kernel|conv_w_kernel|gelu_bwd"),
+    ("framework (torch fills / copies / rng)", r"at::native|rocclr|hiprand"),
+]
+
+
+def load(path):
+    rows = []
+    with open(path, newline="") as fh:
+        for r in csv.DictReader(fh):
+            rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"])))
+    steps = max([c for n, c, _ in rows if "adamw_kernel" in n] or [1])
+    out, kernels = {}, {}
+    for name, calls, ns in rows:
+        label = next((lb for lb, rx in CLASSES if re.search(rx, name)), "other")
+        d = out.setdefault(label, [0.0, 0])
+        d[0] += ns / 1e6 / steps
+        d[1] += calls / steps
+        short = re.sub(r"\(anonymous namespace\)::|void ", "", name).split("(")[0][:70]
+        kernels[short] = (ns / 1e6 / steps, calls / steps, ns / 1e3 / max(calls, 1))
+    return steps, out, kernels
+
+
+def main():
+    steps, a, ka = load(sys.argv[1])
+    total = sum(v[0] for v in a.values())
+    print(f"# {sys.argv[1]}: {steps} steps, kernel-time sum {total:.2f} ms/step")
+    b = None
+    if len(sys.argv) > 2:
+        steps_b, b, kb = load(sys.argv[2])
+        tb = sum(v[0] for v in b.values())
+        print(f"# {sys.argv[2]}: {steps_b} steps, kernel-time sum {tb:.2f} ms/step  (delta {tb - total:+.2f})")
+    print(f"{'class':42s} {'ms/step':>8s} {'launches':>9s}" + (f" {'other':>8s} {'delta':>7s}" if b else ""))
+    for label in sorted(set(a) | set(b or {}), key=lambda k: -(a.get(k, [0])[0])):
+        x = a.get(label, [0.0, 0])
+        line = f"{label:42s} {x[0]:8.3f} {x[1]:9.1f}"
+        if b is not None:
+            y = b.get(label, [0.0, 0])
+            line += f" {y[0]:8.3f} {y[0] - x[0]:+7.3f}"
+        print(line)
+    print("\n# kernels (ms/step, launches/step, us/launch)")
+    for k, v in sorted(ka.items(), key=lambda kv: -kv[1][0])[:40]:
+        print(f"{k:70s} {v[0]:8.3f} {v[1]:7.1f} {v[2]:9.1f}")
+
+
+if __name__ == "__main__":
+    main()

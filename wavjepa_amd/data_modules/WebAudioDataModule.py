@@ -116,6 +116,7 @@ class WebAudioDataModule(_Base):
     SHUFFLE_INITIAL: int = 100
     VERIFY_MD5_CLIPS: int = 64
     MAX_SHARD_FAILURES: int = 16
+    MAX_SAMPLE_FAILURES: int = 1000          # consecutive samples that fail to decode / prepare before the stream raises (= SHUFFLE)
     NUM_WORKERS: int = 16
     PREFETCH_FACTOR: int = 2
 
@@ -150,14 +151,21 @@ class WebAudioDataModule(_Base):
 
     def _samples(self, shards: List[str], rng: random.Random, shuffle: int) -> Iterator[tuple]:
         """Endless stream of prepared samples: raw samples popped from the shuffle buffer, then decoded and prepared."""
-        decoded = 0
+        decoded, failed_in_a_row = 0, 0
         for raw in raw_samples(shards, rng, shuffle, self.SHUFFLE_INITIAL, self.MAX_SHARD_FAILURES):
             try:
                 item = self._retrieve_sample(audio_io.decode_flac(raw["flac"], verify_md5=decoded < self.VERIFY_MD5_CLIPS))
             except Exception as e:                                   # noqa: BLE001  (wds.warn_and_continue: any per-sample failure)
                 warnings.warn(f"{raw.get('__key__')}: {e!r}; skipped")
+                # a corpus in which NOTHING decodes (wrong bit depth, unsupported streams, every clip over the size bound) must not
+                # spin on warnings for ever while the trainer waits for its first batch: readable shards do not count as progress
+                failed_in_a_row += 1
+                if failed_in_a_row >= self.MAX_SAMPLE_FAILURES:
+                    raise RuntimeError(f"{failed_in_a_row} samples in a row failed to decode / prepare (no decodable .flac member in "
+                                       f"{len(shards)} shard(s)?); last error: {e!r}") from e
                 continue
             decoded += 1
+            failed_in_a_row = 0
             yield item
 
     def _batches(self, worker: int, n_workers: int) -> Iterator[tuple]:

@@ -84,6 +84,7 @@ class WebAudioDataModuleDenoiser(_Base):
     SHUFFLE_INITIAL: int = 100
     VERIFY_MD5_CLIPS: int = 64
     MAX_SHARD_FAILURES: int = 16
+    MAX_SAMPLE_FAILURES: int = 1000
 
     def __init__(self, data_dir: str, rir_dir: str, noise_dir: str, batch_size: int = 32, with_noise: bool = False, with_rir: bool = False,
                  nr_samples_per_audio: int = 16, nr_time_points: int = 100, cache_size: int = 1000, snr_low: float = -5.0, snr_high: float = 5.0,
@@ -135,15 +136,20 @@ class WebAudioDataModuleDenoiser(_Base):
         # the shuffle buffer holds RAW samples (webdataset shuffles before decode / map): a prepared item is 10 s of 32 kHz fp32 audio
         # + zero-padded noise + RIR sets, 2.6 GB per worker at 1000 items; decoding, resampling and augmenting happen on the sample
         # popped from the buffer.  Any per-sample failure is reported and skipped (wds.warn_and_continue).
-        batch, decoded = [], 0
+        batch, decoded, failed_in_a_row = [], 0, 0
         for raw in raw_samples(shards, rng, self.SHUFFLE, self.SHUFFLE_INITIAL, self.MAX_SHARD_FAILURES):
             try:
                 item = self._augment_sample(audio_io.decode_flac(raw["flac"], verify_md5=decoded < self.VERIFY_MD5_CLIPS), rir_loader,
                                             noise_loader)
             except Exception as e:                           # noqa: BLE001
                 warnings.warn(f"{raw.get('__key__')}: {e!r}; skipped")
+                failed_in_a_row += 1                         # a corpus in which nothing decodes raises instead of warning for ever
+                if failed_in_a_row >= self.MAX_SAMPLE_FAILURES:
+                    raise RuntimeError(f"{failed_in_a_row} samples in a row failed to decode / prepare (no decodable .flac member in "
+                                       f"{len(shards)} shard(s)?); last error: {e!r}") from e
                 continue
             decoded += 1
+            failed_in_a_row = 0
             batch.append(item)
             if len(batch) == self.batch_size:
                 yield collate(batch)

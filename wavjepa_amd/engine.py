@@ -483,7 +483,10 @@ class JepaEngine:
         self.lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         # fp8 mode: one activation scratch (e4m3 bytes + block scales) per stack (the teacher runs beside the student)
         self._a8, self._a8s = {}, {}
-        for tag, (m, d) in dict(tea=(M, c.d_enc), enc=(Me if train else M, c.d_enc), dec=(Md if train else 0, c.d_dec)).items():
+        # 'enc' is sized for all M rows even when the student's activation buffers follow the ragged row count: infer() runs the
+        # student stack densely (M rows) on whatever arena a training step left behind (N == self.N skips alloc), and the quantiser /
+        # GELU q_out epilogue write M x 4D bytes into this scratch -- with cap_enc rows that was an out-of-bounds device write
+        for tag, (m, d) in dict(tea=(M, c.d_enc), enc=(M, c.d_enc), dec=(Md if train else 0, c.d_dec)).items():
             if m > 0:
                 self._a8[tag] = (_empty(m, 4 * d, dtype=torch.uint8, device=dev),
                                  torch.zeros(ops.fp8_scale_dwords(m, 4 * d), dtype=torch.int32, device=dev))
