@@ -242,10 +242,11 @@ def cpu_baseline(n_clips: int = 4, budget_s: float = 70.0):
         attempt(32, missing or [("base", "fp32")], budget_s - (time.perf_counter() - t_start))
     base = {k: v for k, v in detail.items() if k.startswith("base_fp32@")}
     if not base:
-        return dict(value=None, unit="clips/s", cores=avail, kind="port", cpu=_cpu_model(), sample="no configuration finished inside the bound",
-                    detail=detail)
+        return dict(value=None, unit="clips/s", cores=avail, host_cores=avail, kind="port", cpu=_cpu_model(),
+                    sample="no configuration finished inside the bound", detail=detail)
     key, head = max(base.items(), key=lambda kv: kv[1]["clips_per_s"])
-    return dict(value=head["clips_per_s"], unit="clips/s", cores=head["threads"], kind="port", cpu=_cpu_model(),
+    # cores = the threads the reported value was measured with; host_cores = hardware threads this process may use
+    return dict(value=head["clips_per_s"], unit="clips/s", cores=head["threads"], host_cores=avail, kind="port", cpu=_cpu_model(),
                 sample=f"oracle train step (fwd+EMA+bwd+clip+AdamW), N={n_clips} clips of 2.01 s; value = WavJEPA-base fp32 on {head['threads']} of "
                        f"{avail} host threads, median of {head['timed']} timed steps after {head['warmup']} warm-up ({head['ms_per_step']} ms/step); "
                        f"{time.perf_counter() - t_start:.0f} s of wall clock in all (bounded at {budget_s:.0f} s)",
@@ -307,6 +308,11 @@ def main():
     else:
         source = SyntheticAudioSource(masker, **src_kw)
     runner = StepRunner(model, gradient_clip_val=5.0)
+    # Data-parallel runs leave CUs to RCCL: a persistent GEMM workgroup owns its CU's whole register file and 150 KB of its LDS, so a
+    # channel kernel of the gradient all-reduce can only start on a CU the persistent kernel does not occupy.  28 of 32 workgroups per
+    # XCD leave 32 CUs free (WJ_PERSIST_CUS overrides; StepRunner applies the same default through trainer.init_persist_cus).
+    from wavjepa_amd import ops as _ops
+    persist_cus = _ops.gemm_set_persist_cus(0)
 
     def sync():
         torch.cuda.synchronize()
@@ -469,6 +475,8 @@ def main():
                        # student / predictor run on their visible tokens only unless WJ_RAGGED=0 (same loss and gradients:
                        # the dropped rows are key-masked and carry zero loss weight on the reference)
                        "token_execution": "ragged" if model._engine.ragged else "dense",
+                       # resident workgroups per XCD of the persistent GEMM (32 = every CU; N > 1 leaves CUs to the RCCL kernels)
+                       "persistent_gemm_workgroups_per_xcd": persist_cus,
                        "step_gflop_per_clip_dense": STEP_GFLOP_PER_CLIP,
                        "step_gemm_gflop_per_clip_executed": None if executed_gflop is None else round(executed_gflop / args.clips_per_gpu, 1)},
             # executed GEMM flops (instrumented step) over the measured step time; NOT the dense-shape flop count

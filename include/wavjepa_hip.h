@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 10
+#define WJ_ABI_VERSION 11
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -124,6 +124,12 @@ int wj_wgrad_grouped(const wj_wgrad_group_args*, void* stream);
  * outputs (same k order, bias added last); variant 4 starts its accumulators from the bias: a last-place difference of the bf16 output
  * on <= 0.05 % of the elements. */
 int wj_gemm_set_variant(int variant);
+
+/* Resident workgroups per XCD of the persistent GEMM (1..32; 32 = one per CU, the default; WJ_PERSIST_CUS sets the initial value).
+ * A data-parallel run (train.py:174-179: DDP over 8 GPUs) lowers it so that the RCCL channel kernels of the gradient all-reduce find
+ * free CUs while a persistent GEMM of the backward is resident -- a 150-KiB-LDS workgroup on every CU leaves them none.
+ * workgroups_per_xcd <= 0 only queries.  Returns the previous value. */
+int wj_gemm_set_persist_cus(int workgroups_per_xcd);
 
 /* Diagnostic (tools/persist_stamps.py; only filled when the process runs with WJ_PERSIST_STAMPS=1): copies the time stamps the last
  * persistent-GEMM launch wrote -- [2][256 workgroups][64] s_memrealtime values (100 MHz): start, end of prologue, per output tile the
@@ -505,6 +511,18 @@ typedef struct {
     float lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, grad_scale;
 } wj_adamw_args;
 int wj_adamw_step(const wj_adamw_args*, void* stream);
+
+/* Batched bf16 matrix transposes inside two flat buffers with the same layout: for every table entry (element offset, rows, cols,
+ * first tile) dst[off + c*rows + r] = src[off + r*cols + c].  rows, cols multiples of 64, offsets multiples of 8; n_tiles = sum of
+ * (rows/64)*(cols/64), first tile = running sum.  Keeps W^T shadows of the transformer weights so that the backward's dgrads
+ * (autograd of nn.Linear inside nn.TransformerEncoderLayer, jepa.py:125-131) run as row-form GEMMs.  table is a DEVICE pointer. */
+typedef struct {
+    const void* src;
+    void* dst;
+    const int64_t* table; /* int64 [n_mats][4] */
+    int32_t n_mats, n_tiles;
+} wj_transpose_args;
+int wj_transpose_bf16(const wj_transpose_args*, void* stream);
 
 /* dst_bf16[i] = bf16(src_f32[i]) */
 typedef struct {

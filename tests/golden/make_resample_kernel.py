@@ -44,11 +44,44 @@ def table(orig_freq: int, new_freq: int, method: str) -> np.ndarray:
     return out
 
 
+def table_f32(orig_freq: int, new_freq: int, method: str) -> np.ndarray:
+    """The same closed form with every intermediate rounded to float32, in the order torchaudio evaluates it for a float32 waveform
+    (tap index / orig + phase / new, times base, clamp, window, times pi, sin(t) / t, times window * scale): numpy float32 scalars
+    and scipy's Bessel function -- no torch, no code shared with the product.  The product evaluates the same sequence with torch's
+    float32 kernels; the two may differ in the last place of sin / i0 (the test allows 4 float32 ulps of the largest tap)."""
+    f = np.float32
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    lpw = LPW if method == "kaiser" else 6
+    base = min(orig, new) * (ROLLOFF if method == "kaiser" else 0.99)          # a Python float, as in torchaudio
+    width = math.ceil(lpw * orig / base)
+    out = np.zeros((new, 2 * width + orig), dtype=np.float32)
+    i0b = f(i0(f(BETA)))
+    for p in range(new):
+        for j in range(2 * width + orig):
+            t = f(f(f(-p) / f(new)) + f(f(j - width) / f(orig)))
+            t = f(t * f(base))
+            t = f(min(max(t, f(-lpw)), f(lpw)))
+            if method == "kaiser":
+                r = f(t / f(lpw))
+                w = f(f(i0(f(f(BETA) * f(np.sqrt(f(f(1) - f(r * r))))))) / i0b)
+            else:
+                c = f(np.cos(f(f(f(t * f(math.pi)) / f(lpw)) / f(2))))
+                w = f(c * c)
+            tp = f(t * f(math.pi))
+            s = f(1) if tp == 0 else f(f(np.sin(tp)) / tp)
+            out[p, j] = f(s * f(w * f(base / orig)))
+    return out
+
+
 def main() -> None:
     out = {}
     for o, n, m in PAIRS:
         k = table(o, n, m)
         out[f"{o}_{n}_{m}"] = k
+        k32 = table_f32(o, n, m)
+        out[f"f32:{o}_{n}_{m}"] = k32
+        assert np.abs(k32 - k).max() < 2e-6 * np.abs(k).max() + 2e-7, (o, n, np.abs(k32 - k).max())   # float32 evaluation vs the exact form
         # sanity that follows from the definition: every output phase has (nearly) unit DC gain when the pass band covers DC
         assert abs(k.sum(axis=1) - 1.0).max() < 2e-3, (o, n, k.sum(axis=1))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resample_kernel.npz")

@@ -152,6 +152,28 @@ def test_train_py_two_ranks_share_the_gpu_over_gloo(tmp_path):
 
 
 
+def test_train_py_config1_tiny_model_batch_of_four(tmp_path):
+    """BASELINE config 1's shapes through the launcher: `train.py trainer.size=tiny` = 2-layer student d = 128, 2-layer predictor
+    d = 64, a batch of 4 synthetic 2 s clips (1 source x 4 crops).  BASELINE quotes that configuration on the CPU as a plumbing check;
+    this package has no CPU compute path by design (the product fails loudly without the HIP library and a GPU), so the same launch
+    runs on the GPU.  A few optimisation steps with a 2-step warm-up: finite, and the loss moves."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train.py"), "trainer.size=tiny", "trainer.batch_size=1", "data.samples_per_audio=4",
+           "trainer.steps=6", "trainer.warmup_steps=2", "trainer.log_every_n_steps=1", f"save_dir={tmp_path / 'runs'}"]
+    from tests import launch
+    rc, out, err = launch.run(cmd, cwd=root, timeout=300)
+    assert rc == 0, (out[-1500:], err[-4000:])
+    assert "Effective Batch Size is: 4" in out
+    losses = [float(ln.split("loss")[1].split()[0]) for ln in out.splitlines() if ln.startswith("step ")]
+    assert len(losses) == 6 and all(np.isfinite(losses)) and losses[-1] != losses[0], out[-1500:]
+    import torch
+    ck = torch.load(next((tmp_path / "runs").rglob("last.ckpt")), map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    assert sd["encoder.layers.1.linear1.weight"].shape == (512, 128) and "encoder.layers.2.linear1.weight" not in sd
+    assert sd["decoder.layers.1.self_attn.in_proj_weight"].shape == (192, 64) and sd["post_extraction_mapper.weight"].shape == (128, 512)
+
+
 @pytest.mark.timeout(900)
 def test_train_py_config4_nat_scenes_two_ranks_over_gloo(tmp_path):
     """BASELINE config 4 through the launcher: `train.py extractor=wavjepa_nat data=nat_synthetic masker=AudioSet_nat` under

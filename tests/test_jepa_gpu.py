@@ -130,7 +130,19 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     print(cfg_name, "rel errors vs oracle bf16:", report, "loss hip/oracle-bf16/oracle-fp32:", lo, lr_, l32)
     assert out["local_features"].dtype == torch.float32 and out["preds"].dtype == torch.bfloat16
     assert out["contextual_features"].shape == ref["contextual_features"].shape
+    # distance of each bf16 pipeline from the fp32 truth (same weights, same clips): the HIP path must be as close to it as the oracle's
+    # bf16 flow is.  Two INDEPENDENT bf16 pipelines then sit up to sqrt(2) x that distance apart (measured at 64 clips: 0.86 % between
+    # them with both 0.61-0.63 % from fp32; at 2 clips the rounding errors happen to correlate and 0.66 % is seen), which is what the
+    # fixed bounds of ACT_TOL (1.25 x the 2-clip distances) cannot express for a large batch.
+    to32 = {k: (rel(out[k].float(), ref32[k].float()), rel(ref[k].float(), ref32[k].float())) for k in ("local_features", "targets")}
+    print(cfg_name, "distance from the fp32 oracle (HIP, oracle-bf16):", to32)
+    for k, (d_hip, d_orc) in to32.items():
+        assert d_hip < 1.1 * d_orc + 2e-4, (k, d_hip, d_orc)
     for k, bound in ACT_TOL[cfg_name].items():
+        if n >= 16 and k in to32:
+            bound = max(bound, 1.5 * to32[k][1])
+        elif n >= 16 and k == "contextual_features":
+            bound = max(bound, 1.5 * to32["targets"][1])
         assert report[k] < bound, (k, report[k], bound)
     assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)          # north-star: loss within 1e-3 rel of the bf16 reference flow
     assert abs(lo - l32) < 2e-2 * abs(l32)
@@ -460,6 +472,15 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert line["n_gpus"] == 2 and line["replicas_equal"] is True and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 32 and line["config"]["parallelism"] == "dp2"
     assert abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]      # whole-job clips/s over the slowest rank's time
+    # what a SCALE run will be read by: the all-reduce fields are present and sane before such a run exists
+    ar = line["allreduce"]
+    assert ar is not None and ar["buckets"] >= 2 and ar["steps"] == 3 and 4 * 111012864 <= ar["bytes"] < 4 * 111100000
+    assert ar["backward_window_ms"] is not None and ar["backward_window_ms"] > 0       # first bucket issued BEFORE the backward ended
+    assert ar["exposed_ms"] >= 0 and ar["exposed_ms"] < 1e4
+    assert line["config"]["persistent_gemm_workgroups_per_xcd"] == 28                  # N > 1: CUs left free for the collective
+    # every rank reported its stages (rendezvous, group up, broadcast, first reduced step) on stderr
+    for msg in ("process group up", "parameters broadcast from rank 0", "first optimisation step (all gradient buckets reduced) done"):
+        assert err.count(msg) >= 2, (msg, err[-3000:])
 
 
 @pytest.mark.parametrize("stacks,ragged", [("own", True), ("shared", True), ("own", False)])

@@ -26,7 +26,16 @@ SHAPES = [  # M, N, K, epilogue
     (102912, 512, 1536, ops.EPI_CONV_GELU), (51456, 512, 1024, ops.EPI_CONV_GELU),
     # N % 256 == 128 (last tile column = a half item), N % 256 in (128, 256) (shifted edge tile), a split tail with GELU2 outputs
     (40000, 640, 256, ops.EPI_BIAS_GELU2), (40000, 448, 384, ops.EPI_BF16), (16640, 1024, 256, ops.EPI_BIAS_GELU2), (19000, 1152, 128, ops.EPI_BIAS_GELU),
+    # round 4: the backward through linear2 + GELU on the persistent kernel (gelu' tile read in the store layout, column sums folded in
+    # registers, one atomic per wave; M edges shifted: their duplicate rows must be counted once), incl. a half-width last item
+    (86317, 1536, 384, ops.EPI_MUL_GELU_GRAD), (9907, 3072, 768, ops.EPI_MUL_GELU_GRAD), (33001, 640, 256, ops.EPI_MUL_GELU_GRAD),
+    # round 4: the predictor's dgrads as row-form GEMMs against W^T (N = 384: one full + one half-width item per row panel)
+    (86317, 384, 1152, ops.EPI_BF16), (21600, 384, 1536, ops.EPI_BF16), (21600, 384, 384, ops.EPI_BF16),
+    (5000, 768, 768, ops.EPI_BF16),     # fewer items than resident workgroups (WJ_PERSIST_MIN_TILES=1 sends it to variant 4)
 ]
+only = os.environ.get("WJ_CHECK_ONLY")          # e.g. "2" = the MUL_GELU_GRAD shapes only
+if only is not None:
+    SHAPES = [sh for sh in SHAPES if sh[3] == int(only)]
 ref_v, new_v = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 3
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 
@@ -47,6 +56,11 @@ for (M, N, K, epi) in SHAPES:
         kw.update(seg_rows=402, seg_valid=400)
     if epi in (ops.EPI_BIAS_GELU2, ops.EPI_CONV_GELU):
         C2a, C2b = torch.empty(M, N, device=dev, dtype=bf), torch.empty(M, N, device=dev, dtype=bf)
+    csa = csb = None
+    if epi == ops.EPI_MUL_GELU_GRAD:
+        kw.pop("bias")
+        kw["aux"] = (torch.rand(M, N, device=dev) * 1.2 - 0.1).to(bf)        # gelu' lies in [-0.13, 1.13]
+        csa, csb = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
     worst = 0
     fracs = []
     for r in range(reps):
@@ -54,11 +68,21 @@ for (M, N, K, epi) in SHAPES:
         W = (torch.randn(N, K, device=dev) * 0.05).to(bf)
         Ca = torch.full((M, N), float("nan"), device=dev, dtype=bf)
         Cb = torch.full((M, N), float("nan"), device=dev, dtype=bf)
-        run(ref_v, A, W, Ca, dict(kw, **({"C2": C2a} if C2a is not None else {})))
-        run(new_v, A, W, Cb, dict(kw, **({"C2": C2b} if C2b is not None else {})))
+        if csa is not None:
+            csa.zero_(); csb.zero_()
+        run(ref_v, A, W, Ca, dict(kw, **({"C2": C2a} if C2a is not None else {}), **({"colsum": csa} if csa is not None else {})))
+        run(new_v, A, W, Cb, dict(kw, **({"C2": C2b} if C2b is not None else {}), **({"colsum": csb} if csb is not None else {})))
         torch.cuda.synchronize()
         pairs = [(Ca, Cb)] + ([(C2a, C2b)] if C2a is not None else [])
         same = all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in pairs)
+        if csa is not None:                         # column sums: fp32 sums of the stored bf16 values, in an unspecified order
+            want = Cb.float().sum(0, dtype=torch.float64)
+            scale = Cb.float().abs().sum(0, dtype=torch.float64) + 1e-6
+            for nm, cs in (("ref", csa), ("new", csb)):
+                err = float(((cs.double() - want).abs() / scale).max())
+                if err > 2e-5:
+                    print(f"  COLSUM {nm} M={M} N={N} K={K}: max |err| / sum|x| = {err:.3e}")
+                    same = False
         if not same and 4 in (ref_v, new_v):
             same = True
             for x, y in pairs:
@@ -71,7 +95,7 @@ for (M, N, K, epi) in SHAPES:
             # the variant under test against itself: bit-identical
             Cc = torch.full((M, N), float("nan"), device=dev, dtype=bf)
             C2c = torch.empty_like(C2b) if C2b is not None else None
-            run(new_v, A, W, Cc, dict(kw, **({"C2": C2c} if C2c is not None else {})))
+            run(new_v, A, W, Cc, dict(kw, **({"C2": C2c} if C2c is not None else {}), **({"colsum": torch.zeros_like(csb)} if csb is not None else {})))
             torch.cuda.synchronize()
             same = same and torch.equal(Cb.view(torch.int16), Cc.view(torch.int16)) and (C2c is None or torch.equal(C2b.view(torch.int16), C2c.view(torch.int16)))
         if not same:
@@ -80,8 +104,11 @@ for (M, N, K, epi) in SHAPES:
             print(f"  MISMATCH M={M} N={N} K={K} epi={epi} rep={r}: {int((d > 0).sum())} elements differ, max {float(d.max()):.4g}, "
                   f"nan {int(torch.isnan(Cb.float()).sum())}")
     if r == reps - 1 and M <= 10000:   # fp32 torch reference on the last operands (small shapes)
-        ref = A.float() @ W.float().t() + bias
-        if epi in (ops.EPI_BIAS_GELU, ops.EPI_BIAS_GELU2):
+        ref = A.float() @ W.float().t() + (bias if "bias" in kw else 0)
+        if epi == ops.EPI_MUL_GELU_GRAD:
+            ref = ref.to(bf).float() * kw["aux"].float()
+            got = Cb.float()
+        elif epi in (ops.EPI_BIAS_GELU, ops.EPI_BIAS_GELU2):
             ref = torch.nn.functional.gelu(ref.to(bf).float())
             got = (C2b if epi == ops.EPI_BIAS_GELU2 else Cb).float()
         else:
@@ -97,7 +124,7 @@ for (M, N, K, epi) in SHAPES:
             ops.gemm_set_variant(v)
             e0.record()
             for _ in range(3):
-                ops.gemm(A, W, C, **dict(kw, **({"C2": C2a} if C2a is not None else {})))
+                ops.gemm(A, W, C, **dict(kw, **({"C2": C2a} if C2a is not None else {}), **({"colsum": csa} if csa is not None else {})))
             e1.record()
             torch.cuda.synchronize()
             if r:

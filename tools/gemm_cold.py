@@ -14,6 +14,10 @@ bf = torch.bfloat16
 SHAPES = [(51200, 2304, 768, ops.EPI_BF16), (51200, 768, 3072, ops.EPI_BF16), (51200, 768, 768, ops.EPI_BF16),
           (51200, 3072, 768, ops.EPI_BIAS_GELU), (86317, 1536, 384, ops.EPI_BIAS_GELU2), (86317, 1152, 384, ops.EPI_BF16),
           (86317, 384, 1536, ops.EPI_BF16), (86317, 384, 384, ops.EPI_BF16)]
+SHAPES += [(86317, 1536, 384, ops.EPI_MUL_GELU_GRAD), (9907, 3072, 768, ops.EPI_MUL_GELU_GRAD), (9907, 3072, 768, ops.EPI_BIAS_GELU2),
+           (86317, 384, 1152, ops.EPI_BF16)]
+if os.environ.get("WJ_COLD_EPI"):                  # e.g. "1,2": only these epilogues
+    SHAPES = [sh for sh in SHAPES if str(sh[3]) in os.environ["WJ_COLD_EPI"].split(",")]
 variants = [int(v) for v in sys.argv[1:]] or [3, 4]
 junk = torch.empty(768 * 1024 * 1024 // 4, device=dev)
 for (M, N, K, epi) in SHAPES:
@@ -24,6 +28,9 @@ for (M, N, K, epi) in SHAPES:
     kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=epi, bias=torch.randn(N, device=dev))
     if C2 is not None:
         kw["C2"] = C2
+    if epi == ops.EPI_MUL_GELU_GRAD:
+        kw.pop("bias")
+        kw.update(aux=torch.rand(M, N, device=dev).to(bf), colsum=torch.zeros(N, device=dev))
     out = []
     ts = {(v, mode): [] for v in variants for mode in ("warm", "cold")}
     for r in range(12):                      # the variants interleaved, so that a clock drift hits all of them alike

@@ -62,10 +62,17 @@ struct PArgs {
     char* C;
     char* C2;
     const float* bias;
+    const char* aux;          // MUL_GELU_GRAD: gelu'(h), bf16 [M][ldc]
+    float* colsum;            // MUL_GELU_GRAD: += column sums of C (the bias gradient of the Linear whose output gradient C is)
     unsigned* ctr;            // this launch's 8 counters
     long ldc_b;               // bytes
     unsigned lda_b, ldb_b;    // bytes
-    int M, N, K, tiles_n, ntiles;
+    int M, N, K, ntiles;
+    int items_n;              // work items per 256-row panel: full tiles (the last one shifted inwards if N % 256 is neither 0 nor 128) ...
+    int half_item;            // ... and, if 1, a last HALF-WIDTH item: columns [N - 128, N), the MFMA clusters of phases 1 / 2 skipped
+    int wpx;                  // resident workgroups per XCD (grid = 8 wpx; 32 = every CU)
+    int nostore;              // diagnostic (WJ_PERSIST_DIAG_NOSTORE=1): the epilogue computes but does not store -- what the store path costs
+    int stagger;              // start-up de-phasing: workgroup j of an XCD starts j * stagger / wpx ticks of the 100 MHz clock late
     int seg_rows, seg_valid;
     int active;                   // diagnostic (with stamps): only the first `active` workgroups of every XCD work (32 = all)
     unsigned long long* stamps;   // diagnostic: [256 workgroups][STAMP_N] s_memrealtime values (100 MHz), or NULL
@@ -82,6 +89,16 @@ __device__ __forceinline__ int opaque(int v) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Counted wait behind an epilogue: the LAGF (after a full-width item) / LAGH (after a half-width item) VMEM operations that epilogue
+// issued (stores, the column-sum atomic, the bias DMA) are YOUNGER than the pieces this wait retires and may stay in flight.
+template <int BASE, int LAGF, int LAGH>
+__device__ __forceinline__ void wait_lag(int lag) {
+    if (lag == 0) wait_vmcnt<BASE>();
+    else if (lag == 1) wait_vmcnt<BASE + LAGF>();
+    else if (lag == 2) wait_vmcnt<BASE + LAGH>();
+    else wait_vmcnt<BASE + 1>();                    // diagnostic (no stores issued): only the bias DMA sits in between
 }
 
 // One LDS-DMA instruction: 64 lanes x 16 B from sbase + voff (per lane) to LDS bytes [lds_wave + LDS_CONST + 16 lane).
@@ -104,18 +121,22 @@ struct Bases {
 // One K tile (64 deep) of the stream = four phases; see eight_phase_loop in gemm.hip for the phase / wait structure.
 //   last1: this is the last K tile of its output tile (the Y / B1 pieces staged here belong to the next output tile);
 //   last2: the next K tile is the last one (B0 / X staged here belong to the next output tile);
-//   lag:   first K tile after an epilogue: its LAG VMEM operations (stores + 1 bias DMA) sit between the awaited pieces and the
-//          ones issued here.
+//   lag:   first K tile after an epilogue (1: of a full-width item, 2: of a half-width item; 0: none): its LAGF / LAGH VMEM operations
+//          (stores, the column-sum atomic, 1 bias DMA) sit between the awaited pieces and the ones issued here.
+//   half:  this output item is a half-width one (columns 0-31 of every wave column): the MFMA clusters of phases 1 / 2 (the B1
+//          quadrants) are skipped; every LDS-DMA, wait and barrier stays, so the stream's vmcnt arithmetic is the same for both kinds
+//          (the B1 pieces of a half item are staged from the B0 rows again: in bounds, never multiplied).
 //   FIRST: first PAIR of K tiles of an output tile.  In its PAR == 0 tile every accumulator's first MFMA takes the bias as C (no
 //          clearing, no bias add in the epilogue) and nothing is staged in phases 0 / 1: Y and B1 of the second K tile went out
 //          BEFORE the previous tile's epilogue, so that the waits of the first K-tile pair only retire operations older than
 //          that epilogue's stores (store acknowledgements take ~4 us under load; stores and LDS-DMA share one in-order vmcnt).
 //          Its PAR == 1 tile hands the pulled tile index to the other waves.
-template <int PAR, int LAG, bool FIRST>
+template <int PAR, int LAGF, int LAGH, bool FIRST>
 __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s, const char* nA, const char* nB, unsigned y_skip,
                                         unsigned b1_skip, const unsigned (&vx)[2], const unsigned (&vb)[2], const unsigned (&dx)[2],
                                         const unsigned (&db)[2], unsigned a_lo, unsigned b_lo, bool last1, bool last2, bool has_next,
-                                        bool lag, bool mail, const unsigned& pv, const f32x4 (&bv)[4], unsigned long long* st = nullptr) {
+                                        int lag, bool half, bool mail, const unsigned& pv, const f32x4 (&bv)[4],
+                                        unsigned long long* st = nullptr) {
     constexpr unsigned CUR = PAR * BUF, OTH = (PAR ^ 1) * BUF;
     char* cur = smem + CUR;
     const unsigned a_hi = a_lo ^ 64u, b_hi = b_lo ^ 64u;
@@ -134,8 +155,7 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     if constexpr (FIRST && PAR == 0) {
         // Y(t+1) went out before the previous epilogue (or in the prologue).  Younger than the awaited B1(t): B0, X, Y, B1 of t+1
         // (+ the epilogue's stores and the bias DMA)
-        if (lag) wait_vmcnt<8 + LAG>();
-        else wait_vmcnt<8>();
+        wait_lag<8, LAGF, LAGH>(lag);
     } else if (more1) {
         if constexpr (PAR == 1) {
             if (last1) s.y = nA + y_skip;
@@ -143,8 +163,7 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
         dma<OTH + 8192>(vx[0], s.y, dx[0]); dma<OTH + 8192>(vx[1], s.y, dx[1]);
         s.y += 128;
         if constexpr (FIRST) {                 // PAR == 1: the awaited Y(t), B1(t) are OLDER than the epilogue's stores
-            if (lag) wait_vmcnt<6 + LAG>();
-            else wait_vmcnt<6>();
+            wait_lag<6, LAGF, LAGH>(lag);
         } else {
             wait_vmcnt<6>();
         }
@@ -178,15 +197,17 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!half) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[2 + ni] : acc[mi][2 + ni], 0, 0, 0);
-            acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[mi][2 + ni], 0, 0, 0);
-        }
-    __builtin_amdgcn_s_setprio(0);
+            for (int ni = 0; ni < 2; ++ni) {
+                acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[2 + ni] : acc[mi][2 + ni], 0, 0, 0);
+                acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[mi][2 + ni], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if constexpr (FIRST) { if (st && threadIdx.x == 0) st[PAR * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
@@ -203,15 +224,17 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!half) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[2 + ni] : acc[4 + mi][2 + ni], 0, 0, 0);
-            acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[4 + mi][2 + ni], 0, 0, 0);
-        }
-    __builtin_amdgcn_s_setprio(0);
+            for (int ni = 0; ni < 2; ++ni) {
+                acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni], af[2 * mi], (FIRST && PAR == 0) ? bv[2 + ni] : acc[4 + mi][2 + ni], 0, 0, 0);
+                acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[2 * ni + 1], af[2 * mi + 1], acc[4 + mi][2 + ni], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if constexpr (FIRST) { if (st && threadIdx.x == 0) st[PAR * 4 + 2] = __builtin_amdgcn_s_memrealtime(); }
@@ -224,15 +247,13 @@ __device__ __forceinline__ void pp_tile(f32x4 (&acc)[8][4], char* smem, Bases& s
         dma<CUR>(vx[0], s.x, dx[0]); dma<CUR>(vx[1], s.x, dx[1]);
         s.x += 128;
         if constexpr (PAR == 0 && FIRST) {
-            if (lag) wait_vmcnt<8 + LAG>();
-            else wait_vmcnt<8>();
+            wait_lag<8, LAGF, LAGH>(lag);
         } else {
             wait_vmcnt<8>();
         }
     } else if (more1) {
         if constexpr (PAR == 0 && FIRST) {
-            if (lag) wait_vmcnt<4 + LAG>();
-            else wait_vmcnt<4>();
+            wait_lag<4, LAGF, LAGH>(lag);
         } else {
             wait_vmcnt<4>();
         }
@@ -272,8 +293,16 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, p);
 }
 
-// Number of global stores one wave issues per output tile
-template <int EPI> struct StoreCount { static constexpr int N = (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU) ? 16 : 32; };
+// VMEM operations one wave's epilogue leaves in flight per output item (global stores, + the column-sum atomic of MUL_GELU_GRAD); a
+// half-width item stores 16 rows x 64 B per instruction, i.e. half as many instructions
+template <int EPI, bool HALF> struct StoreCount {
+    static constexpr int OUTS = (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) ? 2 : 1;
+    static constexpr int N = OUTS * (HALF ? 8 : 16) + (EPI == WJ_EPI_MUL_GELU_GRAD ? 1 : 0);
+};
+// LDS-DMA instructions per wave in the block that precedes an output item's first K tile: the bias.  (Tried for MUL_GELU_GRAD: two more
+// that pull one dword of every line of the item's gelu' tile towards the L2 a K loop ahead -- 182.5 against 183.3 us in the step:
+// the tile is read at HBM rate either way, and what the epilogue waits for is the chip-wide burst, not the latency.)
+template <int EPI> struct TopDmaCount { static constexpr int N = 1; };
 
 // 16-byte non-temporal global store: the C tile is not re-read by this kernel, and kept out of the L2's way its operand panels
 // stay resident (measured with tools/persist_stamps.py: 1.30 instead of 1.37 us per K tile on the teacher's QKV shape, and
@@ -282,41 +311,145 @@ __device__ __forceinline__ void store16(char* p, const u32x4& v) {
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 }
 
+// 8 bf16 x 8 bf16 -> 8 bf16 (fp32 product, RNE), and the products' fp32 values added to csum (what the stored bf16 values sum to)
+__device__ __forceinline__ u32x4 mul_bf16x8(const u32x4& v, const u32x4& g, float (&csum)[8], bool count) {
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = __uint_as_float(v[j] << 16), a1 = __uint_as_float(v[j] & 0xffff0000u);
+        const float g0 = __uint_as_float(g[j] << 16), g1 = __uint_as_float(g[j] & 0xffff0000u);
+        const bf16_t p0 = f2bf(a0 * g0), p1 = f2bf(a1 * g1);
+        bf16x2 pk;
+        pk[0] = p0; pk[1] = p1;
+        o[j] = __builtin_bit_cast(unsigned, pk);
+        csum[2 * j] += count ? bf2f(p0) : 0.f;
+        csum[2 * j + 1] += count ? bf2f(p1) : 0.f;
+    }
+    return o;
+}
+
 // accumulators (bias included: it was the C operand of their first MFMA) -> bf16 (-> GELU) -> transposed through LDS -> 16-byte stores.
 // acc[mi][ni][r] = C[m0 + wm*128 + mi*16 + i][n0 + wn*64 + ni*16 + 4 g + r]   (i = lane & 15, g = lane >> 4)
+// (half-width item: ni < 2 only, and the wave's columns are n0 + wn*32 + ni*16 + 4 g + r)
 // In that layout consecutive lanes hold different ROWS, and a wave store whose consecutive lanes touch different cache lines is handled
 // line by line: 2.3 us per 128-KB tile and CU however the lanes are permuted inside the wave, against 0.6 us when every 8 consecutive
 // lanes write one whole 128-B line (tools/micro/store_path.hip).  So each 16-row block takes one trip through a per-wave LDS strip:
 // four 8-byte writes in the MFMA layout, two 16-byte reads with lane -> (row lane >> 3, 16-B chunk lane & 7), two stores of 8 rows x
-// 128 B.  One wave's LDS operations execute in order, so the strip needs neither waits nor barriers between its uses.
-template <int EPI>
-__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, const PArgs& a, int m0, int n0, int wave, int lane) {
+// 128 B (half-width: two writes, one read with lane -> (row lane >> 2, chunk lane & 3), one store of 16 rows x 64 B).  One wave's LDS
+// operations execute in order, so the strip needs neither waits nor barriers between its uses.
+//
+// MUL_GELU_GRAD (the backward through linear2 + GELU: C = bf16(acc) * gelu'(h), and the column sums of C = linear1's bias gradient):
+// the gelu' tile is read in the STORE layout (whole lines), all of its loads issued before anything else; pass 1 packs and transposes
+// the accumulators while they travel, pass 2 multiplies and stores.  The column sums are folded over the wave's 128 rows in registers,
+// transposed across the lane groups with seven shuffles (each lane ends with ONE column) and added with one 256-B atomic per wave.
+// skip_rows: the first rows of a tile that was shifted inwards at the M edge belong to its neighbour as well -- stored twice with the
+// same bits, but counted once.
+template <int EPI, bool HALF>
+__device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, const PArgs& a, int m0, int n0, int skip_rows, int wave,
+                                              int lane) {
+    constexpr int NI = HALF ? 2 : 4;
     const int wm = wave >> 2, wn = wave & 3;
     const int ln = opaque(lane);
     const int i = ln & 15, g = ln >> 4;
     char* strip = smem + STAGE + wave * (16 * STAGE_ROW);
     char* wr = strip + i * STAGE_ROW + g * 8;                                  // + ni * 32
-    const char* rd = strip + (ln >> 3) * STAGE_ROW + (ln & 7) * 16;            // + 8 * STAGE_ROW for rows 8-15
-    const long lane_off = (long)(ln >> 3) * a.ldc_b + (long)(wn * 128 + (ln & 7) * 16);
-    char* c1 = a.C + ((long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2) + lane_off;
+    // store layout: full width lane -> (row ln >> 3 [+ 8], 16-B chunk ln & 7); half width lane -> (row ln >> 2, chunk ln & 3)
+    const int srow = HALF ? (ln >> 2) : (ln >> 3), schunk = HALF ? (ln & 3) : (ln & 7);
+    const char* rd = strip + srow * STAGE_ROW + schunk * 16;                   // + 8 * STAGE_ROW for rows 8-15 (full width)
+    const long lane_off = (long)srow * a.ldc_b + (long)(wn * (HALF ? 64 : 128) + schunk * 16);
+    const long tile_off = (long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2;
+    char* c1 = a.C + tile_off + lane_off;
     char* c2 = nullptr;
-    if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) c2 = a.C2 + ((long)(m0 + wm * 128) * a.ldc_b + (long)n0 * 2) + lane_off;
+    if constexpr (EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_CONV_GELU) c2 = a.C2 + tile_off + lane_off;
     int rem = 0;                                       // CONV_GELU: row % seg_rows, carried from row to row + 16 (seg_rows > 16)
     if constexpr (EPI == WJ_EPI_CONV_GELU) rem = (m0 + wm * 128 + i) % a.seg_rows;
     const long row8 = 8 * a.ldc_b;
-    auto through_strip = [&](const u32x2 (&o)[4], char* dst) {
+    auto transpose = [&](const u32x2 (&o)[NI], u32x4& lo, u32x4& hi) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<u32x2*>(wr + ni * 32) = o[ni];
+        for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<u32x2*>(wr + ni * 32) = o[ni];
         // No instruction; keeps the compiler from moving the strip's writes / reads across these points.  The lanes exchange data
         // through the strip without a barrier hipcc knows of: with a branch around the stores (tried for half-width tiles) it sank the
         // second output's strip WRITES into the branch -- in one thread's view their only reader -- and the lanes outside never wrote.
         __builtin_amdgcn_wave_barrier();
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(rd);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(rd + 8 * STAGE_ROW);
+        lo = *reinterpret_cast<const u32x4*>(rd);
+        if constexpr (!HALF) hi = *reinterpret_cast<const u32x4*>(rd + 8 * STAGE_ROW);
         __builtin_amdgcn_wave_barrier();
-        store16(dst, lo);
-        store16(dst + row8, hi);
     };
+    auto through_strip = [&](const u32x2 (&o)[NI], char* dst) {
+        u32x4 lo, hi;
+        transpose(o, lo, hi);
+        if (a.nostore) {                            // diagnostic: keep the values alive, issue no store
+            asm volatile("" ::"v"(lo));
+            if constexpr (!HALF) asm volatile("" ::"v"(hi));
+            return;
+        }
+        store16(dst, lo);
+        if constexpr (!HALF) store16(dst + row8, hi);
+    };
+    if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
+        const char* ax = a.aux + tile_off + lane_off;
+        u32x4 gl[8], gh[8], tl[8], th[8];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            gl[mi] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + (long)(mi * 16) * a.ldc_b));
+            if constexpr (!HALF) gh[mi] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ax + (long)(mi * 16) * a.ldc_b + row8));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            u32x2 o1[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const f32x4 v = acc[mi][ni];
+                o1[ni] = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            }
+            transpose(o1, tl[mi], th[mi]);
+        }
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int r0 = wm * 128 + srow;                 // tile row of this lane's first output row
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const long off = (long)(mi * 16) * a.ldc_b;
+            store16(c1 + off, mul_bf16x8(tl[mi], gl[mi], csum, r0 + mi * 16 >= skip_rows));
+            if constexpr (!HALF) store16(c1 + off + row8, mul_bf16x8(th[mi], gh[mi], csum, r0 + mi * 16 + 8 >= skip_rows));
+        }
+        // csum[x]: this lane's rows of column schunk * 8 + x.  Fold over the lanes that share a chunk (lane bits 3-5 full width, 2-5
+        // half width), halving the number of columns a lane carries at every step.
+        float c4[4], c2_[2], c1_;
+        {
+            const bool up = HALF ? (ln & 4) : (ln & 8);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float send = up ? csum[x] : csum[4 + x];
+                const float keep = up ? csum[4 + x] : csum[x];
+                c4[x] = keep + __shfl_xor(send, HALF ? 4 : 8, 64);
+            }
+        }
+        {
+            const bool up = HALF ? (ln & 8) : (ln & 16);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const float send = up ? c4[x] : c4[2 + x];
+                const float keep = up ? c4[2 + x] : c4[x];
+                c2_[x] = keep + __shfl_xor(send, HALF ? 8 : 16, 64);
+            }
+        }
+        {
+            const bool up = HALF ? (ln & 16) : (ln & 32);
+            const float send = up ? c2_[0] : c2_[1];
+            const float keep = up ? c2_[1] : c2_[0];
+            c1_ = keep + __shfl_xor(send, HALF ? 16 : 32, 64);
+        }
+        int col;
+        if constexpr (HALF) {
+            c1_ += __shfl_xor(c1_, 32, 64);             // 16 row groups: one more fold, both halves of the wave end with the same sum
+            col = schunk * 8 + ((ln >> 2) & 1) * 4 + ((ln >> 3) & 1) * 2 + ((ln >> 4) & 1);
+            if (ln < 32) atomicAdd(a.colsum + n0 + wn * 32 + col, c1_);
+        } else {
+            col = schunk * 8 + ((ln >> 3) & 1) * 4 + ((ln >> 4) & 1) * 2 + ((ln >> 5) & 1);
+            atomicAdd(a.colsum + n0 + wn * 64 + col, c1_);
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         bool valid = true;
@@ -325,9 +458,9 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, co
             rem += 16;
             rem = rem >= a.seg_rows ? rem - a.seg_rows : rem;
         }
-        u32x2 o1[4], o2[4];                             // [ni]: 4 columns of the first output (C), of the second output (C2)
+        u32x2 o1[NI], o2[NI];                           // [ni]: 4 columns of the first output (C), of the second output (C2)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const f32x4 v = acc[mi][ni];
             if constexpr (EPI == WJ_EPI_BF16) {
                 o1[ni] = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
@@ -368,7 +501,8 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, co
 
 template <int EPI>
 __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
-    constexpr int LAG = StoreCount<EPI>::N + 1;       // + the bias DMA of the block that precedes an output tile's first K tile
+    constexpr int LAGF = StoreCount<EPI, false>::N + TopDmaCount<EPI>::N;   // + the DMAs of the block that precedes an output item's first K tile
+    constexpr int LAGH = StoreCount<EPI, true>::N + TopDmaCount<EPI>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -381,6 +515,9 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     const int qn = a.ntiles >> 3, qr = a.ntiles & 7;
     const int clen = qn + (xl < qr ? 1 : 0);
     const int cstart = xl < qr ? xl * (qn + 1) : qr * (qn + 1) + (xl - qr) * qn;
+    // fewer items than resident workgroups on this XCD label: the spare workgroups leave before they pull, so the counter still sees
+    // exactly clen pulls (one failing pull per WORKING workgroup) and the pull that draws clen - 1 resets it
+    if ((int)(blockIdx.x >> 3) >= clen) return;
     unsigned* ctr = a.ctr + xl * CTR_STRIDE;
     unsigned pv = 0;
     auto pull = [&]() {
@@ -417,37 +554,57 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
         vx[u] = (unsigned)rowx * a.lda_b + (unsigned)(((lane & 7) ^ ((rowx >> 1) & 7)) * 16);
         vb[u] = (unsigned)rowb * a.ldb_b + (unsigned)(((lane & 7) ^ ((rowb >> 1) & 7)) * 16);
     }
-    const unsigned y_skip = 64u * a.lda_b, b1_skip = 32u * a.ldb_b;
-    auto tile_coords = [&](int q, int& m0, int& n0) {
+    const unsigned y_skip = 64u * a.lda_b, b1_full = 32u * a.ldb_b;
+    // A half-width item covers columns [n0, n0 + 128): wave column wn owns n0 + 32 wn .. + 31, staged where the B0 rows of a full
+    // tile go (LDS rows 64 wn .. + 31).  Its per-lane source offsets are those of a full tile minus 32 wn rows: a wave-uniform
+    // term, folded into the scalar base.
+    const long half_adj = (long)((wave >> 1) * 32) * a.ldb_b;
+    auto tile_coords = [&](int q, int& m0, int& n0, bool& half, int& skip) {
         const int L = cstart + q;
-        const int tm = L / a.tiles_n;
+        const int tm = L / a.items_n;
+        const int j = L - tm * a.items_n;
         m0 = min(tm * 256, a.M - 256);                 // edge tiles are shifted inwards
-        n0 = min((L - tm * a.tiles_n) * 256, a.N - 256);
+        skip = tm * 256 - m0;                          // rows of a shifted tile that its neighbour owns
+        half = a.half_item && j == a.items_n - 1;
+        n0 = half ? a.N - 128 : min(j * 256, a.N - 256);
     };
     const char* bias_src = a.bias ? reinterpret_cast<const char*>(a.bias) : reinterpret_cast<const char*>(g_zero_bias);
-    auto bias_dma = [&](int n0, int slot) {
-        // this wave's 64 bias values -> its LDS slot: lanes 0-15, 16 B each
+    auto bias_dma = [&](int n0, bool half, int slot) {
+        // this wave's 64 (half-width item: 32) bias values -> its LDS slot: lanes 0-15 (0-7), 16 B each
         const int ln = opaque(lane);
-        const unsigned bias_v = a.bias ? (unsigned)((wn * 64 + (ln & 15) * 4) * 4) : (unsigned)((ln & 15) * 16);
+        const unsigned bias_v = a.bias ? (unsigned)((wn * (half ? 32 : 64) + (ln & 15) * 4) * 4) : (unsigned)((ln & 15) * 16);
         const char* sb = a.bias ? bias_src + (long)n0 * 4 : bias_src;
         const unsigned dst = lds0 + AUX + (unsigned)(slot * 2048 + wave * 256);
-        asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffff\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
-                     ::"v"(bias_v), "s"(sb), "s"(dst) : "memory", "m0");
+        if (half)
+            asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xff\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                         ::"v"(bias_v), "s"(sb), "s"(dst) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, 0xffff\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                         ::"v"(bias_v), "s"(sb), "s"(dst) : "memory", "m0");
     };
 
     f32x4 acc[8][4];                                   // defined by the first K tile of every output tile (C = 0 there)
 
     if (a.stamps && (int)(blockIdx.x >> 3) >= a.active) return;   // diagnostic: a partly idle chip (WJ_PERSIST_ACTIVE)
+    if (a.stagger > 0) {
+        // All workgroups start together and every item takes the same time, so the whole chip alternates between a K-loop phase
+        // (matrix pipe busy, HBM idle) and an epilogue phase (every CU reads / writes its 128-256 KB at once, matrix pipe idle).
+        // Spreading the starts over one item time lets one workgroup's epilogue traffic travel while its neighbours multiply.
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)((long)(blockIdx.x >> 3) * a.stagger / a.wpx);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
 
     // ---- prologue: first tile is static; pull the second
-    int m0, n0;
-    tile_coords(blockIdx.x >> 3, m0, n0);
+    int m0, n0, skip0;
+    bool half0;
+    tile_coords(blockIdx.x >> 3, m0, n0, half0, skip0);
     Bases s;
     s.x = a.A + (long)m0 * a.lda_b;
     s.y = s.x + y_skip;
-    s.b0 = a.B + (long)n0 * a.ldb_b;
-    s.b1 = s.b0 + b1_skip;
-    bias_dma(n0, 0);
+    s.b0 = a.B + (long)n0 * a.ldb_b - (half0 ? half_adj : 0);
+    s.b1 = s.b0 + (half0 ? 0u : b1_full);
+    bias_dma(n0, half0, 0);
     pull();
     dma<0>(vx[0], s.x, dx[0]); dma<0>(vx[1], s.x, dx[1]);
     dma<BOFF>(vb[0], s.b0, db[0]); dma<BOFF>(vb[1], s.b0, db[1]);
@@ -468,7 +625,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     unsigned mail_v = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
     mail_v = __builtin_amdgcn_readfirstlane(mail_v);
     if (mail_v == (unsigned)(clen - 1) && t == 0) atomicExch(ctr, 0u);   // the launch's last pull on this counter: reset it
-    int q_next = 32 + (int)mail_v;
+    int q_next = a.wpx + (int)mail_v;
     bool has_next = q_next < clen;
 
     const int i = lane & 15, g = lane >> 4;
@@ -478,22 +635,24 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     stamp();
     if (wm == 1) __builtin_amdgcn_s_barrier();        // waves 4-7 run one barrier behind
 
-    bool lag = false;
+    int lag = 0;
     int slot = 0;
     int tile_iter = 0;                                // diagnostic (phase stamps)
     for (;;) {
         // ---- before the first K tile of an output tile: where the next one starts, its bias, and the pull for the one after
-        int m1 = m0, n1 = n0;
+        int m1 = m0, n1 = n0, skip1 = skip0;
+        bool half1 = half0;
         const bool pulled = has_next;
         const char* nA = a.A;
         const char* nB = a.B;
         if (has_next) {
-            tile_coords(q_next, m1, n1);
+            tile_coords(q_next, m1, n1, half1, skip1);
             nA = a.A + (long)m1 * a.lda_b;
-            nB = a.B + (long)n1 * a.ldb_b;
+            nB = a.B + (long)n1 * a.ldb_b - (half1 ? half_adj : 0);
         }
+        const unsigned b1_skip = half1 ? 0u : b1_full;  // of the NEXT item: where its B1 pieces come from
         __builtin_amdgcn_sched_barrier(0);
-        bias_dma(n1, slot ^ 1);                        // always exactly one DMA here (the LAG count relies on it)
+        bias_dma(n1, half1, slot ^ 1);                 // always exactly TopDmaCount DMAs here (the LAG counts rely on it)
         if (pulled) pull();
         __builtin_amdgcn_sched_barrier(0);
         f32x4 bv[4];                                   // bias of this lane's 16 columns: the accumulators start from it
@@ -505,16 +664,16 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
         }
         unsigned long long* st = (a.stamps && tile_iter < 7) ? a.stamps + 256 * STAMP_N + blockIdx.x * STAMP_N + tile_iter * 8 : nullptr;
         ++tile_iter;
-        pp_tile<0, LAG, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, 2 == n, has_next, lag, false, pv,
-                              bv, st);
-        pp_tile<1, LAG, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, 2 == n, false, has_next, lag,
-                              pulled && wave == 0, pv, bv, st);
+        pp_tile<0, LAGF, LAGH, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, 2 == n, has_next, lag, half0,
+                                     false, pv, bv, st);
+        pp_tile<1, LAGF, LAGH, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, 2 == n, false, has_next, lag, half0,
+                                     pulled && wave == 0, pv, bv, st);
         stamp();                                       // diagnostic: end of the first two K tiles
         for (int kt = 2; kt < n; kt += 2) {
-            pp_tile<0, LAG, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, kt + 2 == n, has_next, false,
-                                   false, pv, bv);
-            pp_tile<1, LAG, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, kt + 2 == n, false, has_next, false,
-                                   false, pv, bv);
+            pp_tile<0, LAGF, LAGH, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, kt + 2 == n, has_next, 0,
+                                          half0, false, pv, bv);
+            pp_tile<1, LAGF, LAGH, false>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, kt + 2 == n, false, has_next, 0,
+                                          half0, false, pv, bv);
         }
         if (has_next) {
             // Y, B1 of the next tile's SECOND K tile, before this tile's stores (see FIRST above).  Their slots (odd parity) were last
@@ -531,13 +690,14 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
         // 0-3 here and one for waves 4-7 behind the epilogue keep the lag and put both epilogues side by side.
         if (wm == 0) __builtin_amdgcn_s_barrier();
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA results of the last phase -> VALU readers behind the loop branch
-        epilogue_regs<EPI>(acc, smem, a, m0, n0, wave, lane);
+        if (half0) epilogue_regs<EPI, true>(acc, smem, a, m0, n0, skip0, wave, lane);
+        else epilogue_regs<EPI, false>(acc, smem, a, m0, n0, skip0, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (wm == 1) __builtin_amdgcn_s_barrier();
         stamp();
         if (!has_next) break;
-        lag = true;                                    // every tile issues all of its stores (edge tiles are shifted, not clipped)
-        m0 = m1; n0 = n1;
+        lag = a.nostore ? 3 : (half0 ? 2 : 1);         // every item issues all of its stores (edge tiles are shifted, not clipped)
+        m0 = m1; n0 = n1; half0 = half1; skip0 = skip1;
         slot ^= 1;
         if (pulled) {
             // the word wave 0 wrote in the second K tile of the tile just finished (>= 2 barriers ago for either wave group; the next
@@ -545,7 +705,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
             unsigned mv = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
             mv = __builtin_amdgcn_readfirstlane(mv);
             if (mv == (unsigned)(clen - 1) && t == 0) atomicExch(ctr, 0u);
-            q_next = 32 + (int)mv;
+            q_next = a.wpx + (int)mv;
             has_next = q_next < clen;
         }
     }
@@ -562,15 +722,59 @@ SlotTable& table() {
     return t;
 }
 
+// Work items of one 256-row panel: N / 256 full tiles, then a half-width item when N % 256 == 128 (WJ_PERSIST_HALF=0: a shifted full
+// tile instead, the round-3 behaviour), or a full tile shifted inwards for any other remainder.
+struct Items { int items_n, half_item; };
+Items items_of(const wj_gemm_args* a) {
+    static int half_ok = -1;
+    if (half_ok < 0) { const char* v = getenv("WJ_PERSIST_HALF"); half_ok = v ? atoi(v) : 1; }
+    Items it;
+    it.half_item = (half_ok && a->N % 256 == 128) ? 1 : 0;
+    it.items_n = it.half_item ? a->N / 256 + 1 : (a->N + 255) / 256;
+    return it;
+}
+
+// Resident workgroups per XCD (WJ_PERSIST_CUS=n, 1..32, default 32 = one per CU).  A data-parallel run sets it below 32 so that an
+// RCCL channel kernel finds free CUs while a persistent GEMM is resident (bench.py --gpus N > 1 / trainer: WJ_PERSIST_CUS unset ->
+// wj_gemm_set_persist_cus).
+int g_persist_wpx = 0;
+int persist_wpx() {
+    if (g_persist_wpx == 0) {
+        const char* v = getenv("WJ_PERSIST_CUS");
+        int w = v ? atoi(v) : 32;
+        g_persist_wpx = w < 1 ? 1 : (w > 32 ? 32 : w);
+    }
+    return g_persist_wpx;
+}
+
+// Start-up spread in ticks of the 100 MHz clock.  WJ_PERSIST_STAGGER_US=<us> applies to every launch; unset: 0.
+int persist_stagger(const wj_gemm_args* a) {
+    static int us = -1;
+    if (us < 0) { const char* v = getenv("WJ_PERSIST_STAGGER_US"); us = v ? atoi(v) : 0; }
+    static int only = -2;                           // WJ_PERSIST_STAGGER_EPI=<epilogue>: only launches with that epilogue (A/B runs)
+    if (only == -2) { const char* v = getenv("WJ_PERSIST_STAGGER_EPI"); only = v ? atoi(v) : -1; }
+    if (only >= 0 && a->epilogue != only) return 0;
+    return us * 100;
+}
+
 template <int EPI>
 int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev) {
     PArgs p;
     p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C; p.C2 = (char*)a->C2; p.bias = (const float*)a->bias;
+    p.aux = (const char*)a->aux; p.colsum = a->colsum;
     p.ctr = ctr;
     p.ldc_b = a->ldc * 2; p.lda_b = (unsigned)(a->lda * 2); p.ldb_b = (unsigned)(a->ldb * 2);
     p.M = a->M; p.N = a->N; p.K = a->K;
-    p.tiles_n = (a->N + 255) / 256;
-    p.ntiles = ((a->M + 255) / 256) * p.tiles_n;
+    const Items it = items_of(a);
+    p.items_n = it.items_n; p.half_item = it.half_item;
+    p.ntiles = ((a->M + 255) / 256) * p.items_n;
+    p.wpx = persist_wpx();
+    p.stagger = persist_stagger(a);
+    {
+        static int ns = -1;
+        if (ns < 0) { const char* v = getenv("WJ_PERSIST_DIAG_NOSTORE"); ns = v ? atoi(v) : 0; }
+        p.nostore = (ns && a->epilogue != WJ_EPI_MUL_GELU_GRAD) ? 1 : 0;
+    }
     p.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1;
     p.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     {
@@ -591,7 +795,7 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) return WJ_ERR_LAUNCH;
         lds_ok[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(256), dim3(NT), LDS_TOTAL, s, p);
+    hipLaunchKernelGGL(kern, dim3(8 * p.wpx), dim3(NT), LDS_TOTAL, s, p);
     WJ_CHECK_LAUNCH();
     if (p.active < 32) (void)hipMemsetAsync(ctr, 0, 8 * CTR_STRIDE * sizeof(unsigned), s);   // diagnostic: idle workgroups made no pulls, the counters did not wrap
     return WJ_OK;
@@ -600,16 +804,35 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
 }  // namespace
 
 bool wj_gemm_persist_eligible(const wj_gemm_args* a) {
-    if (a->a_trans || a->b_trans || a->rowmap || a->colsum || a->split_k > 1) return false;
+    if (a->a_trans || a->b_trans || a->rowmap || a->split_k > 1) return false;
     if (a->K < 128 || (a->K % 128) || a->M < 256 || a->N < 256) return false;
     const int e = a->epilogue;
-    if (e != WJ_EPI_BF16 && e != WJ_EPI_BIAS_GELU2 && e != WJ_EPI_BIAS_GELU && e != WJ_EPI_CONV_GELU) return false;
+    if (e != WJ_EPI_BF16 && e != WJ_EPI_BIAS_GELU2 && e != WJ_EPI_BIAS_GELU && e != WJ_EPI_CONV_GELU && e != WJ_EPI_MUL_GELU_GRAD) return false;
     if ((e == WJ_EPI_BIAS_GELU2 || e == WJ_EPI_CONV_GELU) && !a->C2) return false;
     if (e == WJ_EPI_CONV_GELU && a->seg_rows > 0 && a->seg_rows <= 16) return false;
-    const long tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    if (tiles < 256) return false;
+    // MUL_GELU_GRAD: the register epilogue always folds the column sums (one atomic per wave and item is part of its vmcnt
+    // arithmetic), and columns must not be computed twice (no shifted last tile column)
+    if (e == WJ_EPI_MUL_GELU_GRAD) {
+        if (!a->aux || !a->colsum || ((uintptr_t)a->aux & 15) || a->bias) return false;
+        if (a->N % 256 != 0 && !items_of(a).half_item) return false;      // a shifted last tile column would add its columns twice
+    }
+    if (e != WJ_EPI_MUL_GELU_GRAD && a->colsum) return false;
+    // 16-byte vector stores / LDS-DMA at every tile origin (wj_gemm_bf16 already requires N, lda, ldb, ldc % 8 == 0 and 16-byte
+    // aligned A / B / C; stated here as well because the shifted / half-width edge items start at N - 256 / N - 128)
+    if ((a->N & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 7)) return false;
+    if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2 | (uintptr_t)a->bias) & 15) return false;
+    static int min_tiles = -1;                      // WJ_PERSIST_MIN_TILES: smallest item count that takes the persistent kernel
+    if (min_tiles < 0) { const char* v = getenv("WJ_PERSIST_MIN_TILES"); min_tiles = v ? atoi(v) : 256; }
+    const long tiles = (long)((a->M + 255) / 256) * items_of(a).items_n;
+    if (tiles < min_tiles) return false;
     if (a->lda * 2 * 256 >= (1l << 31) || a->ldb * 2 * 256 >= (1l << 31)) return false;   // 32-bit per-lane offsets inside a tile
     return true;
+}
+
+extern "C" int wj_gemm_set_persist_cus(int workgroups_per_xcd) {
+    const int prev = persist_wpx();
+    if (workgroups_per_xcd > 0) g_persist_wpx = workgroups_per_xcd > 32 ? 32 : workgroups_per_xcd;
+    return prev;
 }
 
 // diagnostic: copy the stamp buffer to the host (synchronises the device)
@@ -647,6 +870,7 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
         case WJ_EPI_BIAS_GELU2: return launch_persist<WJ_EPI_BIAS_GELU2>(a, s, ctr, dev);
         case WJ_EPI_BIAS_GELU: return launch_persist<WJ_EPI_BIAS_GELU>(a, s, ctr, dev);
         case WJ_EPI_CONV_GELU: return launch_persist<WJ_EPI_CONV_GELU>(a, s, ctr, dev);
+        case WJ_EPI_MUL_GELU_GRAD: return launch_persist<WJ_EPI_MUL_GELU_GRAD>(a, s, ctr, dev);
         default: return WJ_ERR_UNSUPPORTED;
     }
 }

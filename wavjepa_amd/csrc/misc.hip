@@ -467,6 +467,43 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
 }
 
+// ------------------------------------------------------------------------------------------- batched bf16 transposes (W^T shadows)
+// dst[off + c * rows + r] = src[off + r * cols + c] for every matrix of the table: the bf16 weight shadows of the transformer stacks,
+// transposed once per step so that every dgrad dx = dy . W runs as a ROW-form GEMM against W^T (the persistent eight-phase kernel)
+// instead of the col-form 256 x 128 schedule.  One workgroup per 64 x 64 tile: 16-byte reads along the source rows, a padded LDS
+// tile (pitch 66 elements: the column walk of the transposed read touches 32 distinct banks), 16-byte writes along the destination
+// rows.  table: int64 [n_mats][4] = (element offset, rows, cols, first tile of the matrix in the launch's tile list).
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(wj_transpose_args a) {
+    __shared__ bf16_t tile[64][66];
+    const int t = threadIdx.x;
+    int q = 0;
+#pragma unroll 1
+    for (int x = 1; x < a.n_mats; ++x)
+        if ((long)blockIdx.x >= a.table[4 * x + 3]) q = x;
+    const long off = a.table[4 * q], rows = a.table[4 * q + 1], cols = a.table[4 * q + 2];
+    const int local = (int)(blockIdx.x - a.table[4 * q + 3]);
+    const int tiles_c = (int)(cols / 64);
+    const int tr = local / tiles_c, tc = local - tr * tiles_c;
+    const bf16_t* src = (const bf16_t*)a.src + off + (long)(tr * 64) * cols + tc * 64;
+    bf16_t* dst = (bf16_t*)a.dst + off + (long)(tc * 64) * rows + tr * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (t >> 3) + 32 * u, c8 = (t & 7) * 8;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)r * cols + c8);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) tile[r][c8 + x] = v[x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = (t >> 3) + 32 * u, r8 = (t & 7) * 8;       // destination row c (a source column), 8 source rows r8 ..
+        bf16x8 v;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v[x] = tile[r8 + x][c];
+        *reinterpret_cast<bf16x8*>(dst + (long)c * rows + r8) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- crop + normalise
 __global__ __launch_bounds__(1024) void crop_kernel(wj_crop_args a) {
     __shared__ float red[16];
@@ -515,7 +552,7 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
     WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args) WJ_SZ(wj_spin_args)
-    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args)
+    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args)
 #undef WJ_SZ
     return -1;
 }
@@ -546,7 +583,7 @@ extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     static const char* const none[] = {"wj_gemm_bf16", "wj_layernorm_fwd", "wj_colsum_bf16", "wj_colsum_f32", "wj_attn_fwd", "wj_gelu_bwd_bf16",
         "wj_conv_weight_layout", "wj_add_pos", "wj_mask_gather_rows", "wj_mask_scatter_fill_pos", "wj_mask_scatter_fill_pos_bwd",
         "wj_unmask_rows_f32", "wj_instnorm_accumulate", "wj_instnorm_mean", "wj_ema_update", "wj_adamw_step", "wj_cast_f32_to_bf16",
-        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir"};
+        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir", "wj_transpose_bf16"};
     for (const char* n : none)
         if (!strcmp(fn, n)) return 0;
     return -1;
@@ -717,6 +754,15 @@ extern "C" int wj_adamw_step(const wj_adamw_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n / 4, 256)), dim3(256), 0, STREAM, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+extern "C" int wj_transpose_bf16(const wj_transpose_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
+    if (!a || !a->src || !a->dst || !a->table || a->n_mats <= 0 || a->n_tiles <= 0) return WJ_ERR_ARG;
+    if (((uintptr_t)a->src | (uintptr_t)a->dst) & 15) return WJ_ERR_ARG;
+    hipLaunchKernelGGL(transpose_tiles_kernel, dim3(a->n_tiles), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

@@ -67,6 +67,7 @@ class DenoiserEngine(JepaEngine):
         c, f = self.cfg, self.flat
         De, M, N2 = c.d_enc, self.M, self.N
         f.g32.zero_()
+        self.refresh_wt()
         bw = self.bw["enc"]
         ops.mse_groups(self.enc_out, self.dn_targets, self.dn_w, self.dn_loss, self.dn_ws, n=self.dn_n, G=2, dpreds=bw["dx1"],
                        gscale=gscale_ptr if gscale_ptr else None)

@@ -193,7 +193,9 @@ def conv_active_rows(keep: np.ndarray, P: Sequence[int], spec) -> Dict[int, Tupl
 class _Layer:
     """Raw device pointers of one transformer layer (weights bf16, biases / LN params fp32, gradients fp32)."""
     __slots__ = ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "g1", "be1", "g2", "be2",
-                 "gwqkv", "gbqkv", "gwo", "gbo", "gw1", "gb1", "gw2", "gb2", "gg1", "gbe1", "gg2", "gbe2")
+                 "gwqkv", "gbqkv", "gwo", "gbo", "gw1", "gb1", "gw2", "gb2", "gg1", "gbe1", "gg2", "gbe2",
+                 "wqkv_name", "wo_name", "w1_name", "w2_name",      # parameter names of the weights (student stacks)
+                 "wqkvT", "woT", "w1T", "w2T")                      # bf16 W^T shadows (row-form dgrads), when the engine keeps them
 
 
 def _layer_ptrs(flat: FlatParams, prefix: str, teacher: bool) -> _Layer:
@@ -210,6 +212,8 @@ def _layer_ptrs(flat: FlatParams, prefix: str, teacher: bool) -> _Layer:
         else:
             setattr(L, k, flat.ptr16(full) if is_w else flat.ptr32(full))
             setattr(L, "g" + k, flat.gptr(full))
+            if is_w:
+                setattr(L, k + "_name", full)
     return L
 
 
@@ -262,7 +266,12 @@ class JepaEngine:
         self._a8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}               # per stack: activation scratch (q, scales)
         self.side = self._pick_side_stream() if self.use_side else torch.cuda.Stream(device=self.dev)
         self.has_mapper = "post_extraction_mapper.weight" in flat.by_name
+        # dgrads dx = dy . W as ROW-form GEMMs against bf16 W^T shadows of the transformer weights (refreshed once per step by one
+        # batched transpose, wj_transpose_bf16): the persistent eight-phase kernel instead of the col-form 256 x 128 schedule.
+        # WJ_WT_DGRAD=0 keeps the col-form dgrads (A/B runs).
+        self.wt_dgrad = _os.environ.get("WJ_WT_DGRAD", "1") != "0"
         self._bind_params()
+        self._bind_wt()
         self._conv_w: Dict[str, torch.Tensor] = {}
         self._alloc_conv_weights()
 
@@ -318,6 +327,34 @@ class JepaEngine:
         self.enc_layers = [_layer_ptrs(f, f"encoder.layers.{i}.", False) for i in range(c.l_enc)]
         self.dec_layers = [_layer_ptrs(f, f"decoder.layers.{i}.", False) for i in range(c.l_dec)]
         self.tea_layers = [_layer_ptrs(f, f"teacher_encoder.layers.{i}.", True) for i in range(c.l_enc)]
+
+    def _bind_wt(self) -> None:
+        """W^T shadows: one more bf16 buffer with the parameter layout, every 2-D transformer weight stored transposed at its own offset."""
+        f = self.flat
+        self._wt_table, self._wt_n, self._wt_tiles, self.p16t = None, 0, 0, None
+        if self.wt_dgrad:
+            rows, tiles = [], 0
+            for w in self.enc_layers + self.dec_layers:
+                for k in ("wqkv", "wo", "w1", "w2"):
+                    s = f.by_name[getattr(w, k + "_name")]
+                    r, cc = s.shape
+                    if r % 64 or cc % 64:
+                        rows = None
+                        break
+                    rows.append((s.offset, r, cc, tiles))
+                    tiles += (r // 64) * (cc // 64)
+                if rows is None:
+                    break
+            if rows:
+                self.p16t = torch.zeros(f.n, dtype=torch.bfloat16, device=self.dev)
+                self._wt_table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+                self._wt_n, self._wt_tiles = len(rows), tiles
+                for w in self.enc_layers + self.dec_layers:
+                    for k in ("wqkv", "wo", "w1", "w2"):
+                        setattr(w, k + "T", self.p16t.data_ptr() + 2 * f.by_name[getattr(w, k + "_name")].offset)
+            else:
+                self.wt_dgrad = False          # a width that is not a multiple of 64: keep the col-form dgrads
+        self._wt_fresh = False
 
     def _alloc_conv_weights(self) -> None:
         C = self.C
@@ -376,6 +413,7 @@ class JepaEngine:
             f.bf16_fresh = True
         if self.fp8:
             self._fp8_weights()
+        self._wt_fresh = False                      # the shadows follow p16; refreshed by the first backward that needs them
         C = self.C
         for si, pre in enumerate(self.stacks):
             for l, (_, k, s) in enumerate(self.cfg.conv_spec):
@@ -614,6 +652,24 @@ class JepaEngine:
         ops.gemm_mxfp8(q, w8[0], sc, w8[1], out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ld_scale_a=M, ld_scale_b=N, epilogue=epilogue, C2=C2,
                        bias=bias, **extra)
 
+    def refresh_wt(self) -> None:
+        """bf16 W^T shadows from the current bf16 weights (one batched transpose; once per prepared set of weights)."""
+        if self.wt_dgrad and not self._wt_fresh:
+            ops.transpose_bf16(self.flat.p16, self.p16t, self._wt_table, self._wt_n, self._wt_tiles)
+            self._wt_fresh = True
+
+    def _dgrad(self, dY, w: _Layer, key: str, out, *, M: int, N: int, K: int, **kw) -> None:
+        """out[M, N] = dY[M, K] . W   (W = the layer's `key` weight, stored [K][N] as nn.Linear keeps it): against the W^T shadow as a
+        row-form GEMM, or (WJ_WT_DGRAD=0, widths that are not multiples of 64) against W itself in col form."""
+        # only where the row-form product fills the persistent kernel (>= 256 work items of 256 rows x 256 / 128 columns): measured in
+        # the step, the student's 117-tile dgrads (M ~ 10 k context rows, N = 768) run 58 / 47 / 20 us in col form on the 256 x 128
+        # schedule (234 workgroups) against 64 / 49 / 24 us in row form on the one-tile eight-phase schedule
+        items = -(-M // 256) * (N // 256 + (1 if N % 256 else 0))
+        if self.wt_dgrad and items >= 256:
+            ops.gemm(dY, getattr(w, key + "T"), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+        else:
+            ops.gemm(dY, getattr(w, key), out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, **kw)
+
     def _wgrad(self, dY, X, gW, n_out: int, k_in: int, m_tok: int) -> None:
         """gW[n_out, k_in] += dY[m_tok, n_out]^T @ X[m_tok, k_in]"""
         ops.gemm(dY, X, gW, M=n_out, N=k_in, K=m_tok, lda=n_out, ldb=k_in, ldc=k_in, a_trans=1, b_trans=1,
@@ -662,18 +718,18 @@ class JepaEngine:
         dgb, dxb = bw["dgb"], bw["dxb"]
         ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, dy2=dyb, dy2_is_bf16=dyb is not None, ds_f32=ds, ds_bf16=dsb2,
                           dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2, workspace=self.red_ws)
-        ops.gemm(dsb2, w.w2, dh, M=M, N=4 * D, K=D, lda=D, ldb=4 * D, ldc=4 * D, b_trans=1, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
-                 colsum=w.gb1)           # linear1.bias gradient = column sums of dh, fused into the producing epilogue
+        self._dgrad(dsb2, w, "w2", dh, M=M, N=4 * D, K=D, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
+                    colsum=w.gb1)        # linear1.bias gradient = column sums of dh, fused into the producing epilogue
 
         bw["pending"] += [(dsb2, a.g, w.gw2, D, 4 * D, M), (dh, a.x1b, w.gw1, 4 * D, D, M)]
-        ops.gemm(dh, w.w1, dgb, M=M, N=D, K=4 * D, lda=4 * D, ldb=D, ldc=D, b_trans=1)
+        self._dgrad(dh, w, "w1", dgb, M=M, N=D, K=4 * D)
         ops.layernorm_bwd(ds, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, dy2=dgb, dy2_is_bf16=True, ds_f32=ds, ds_bf16=dsb1,
                           dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo, workspace=self.red_ws)      # ds updated in place
         ds_all = ds
         if sub is None:
-            ops.gemm(dsb1, w.wo, do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+            self._dgrad(dsb1, w, "wo", do, M=M, N=D, K=D)
         else:                             # back to all rows: zero gradient where no output was used
-            ops.gemm(dsb1, w.wo, self.tail_do, M=M, N=D, K=D, lda=D, ldb=D, ldc=D, b_trans=1)
+            self._dgrad(dsb1, w, "wo", self.tail_do, M=M, N=D, K=D)
             ops.unmask_rows_f32(self.tail_do, sub[1], do, M=Mall, D=D, dst_is_bf16=True)
             ops.unmask_rows_f32(ds, sub[1], dx1, M=Mall, D=D, src_is_f32=True)       # dx1 is free again: residual gradient
             ds_all = dx1
@@ -697,9 +753,9 @@ class JepaEngine:
                         bw["used"][sl] = True
             self._on_side(wgrads)
         if bottom:
-            ops.gemm(dqkv, w.wqkv, dx_out, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1, epilogue=ops.EPI_ADD_F32, aux=ds_all)
+            self._dgrad(dqkv, w, "wqkv", dx_out, M=Mall, N=D, K=3 * D, epilogue=ops.EPI_ADD_F32, aux=ds_all)
             return dx_out, None, flush
-        ops.gemm(dqkv, w.wqkv, dxb, M=Mall, N=D, K=3 * D, lda=3 * D, ldb=D, ldc=D, b_trans=1)
+        self._dgrad(dqkv, w, "wqkv", dxb, M=Mall, N=D, K=3 * D)
         return ds_all, dxb, flush
 
     # ------------------------------------------------------------------------------------------------ front-end
@@ -752,7 +808,11 @@ class JepaEngine:
         self._frontend(audio)
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
-        self._on_side(self._teacher_targets)
+        def beside():
+            self._teacher_targets()
+            if torch.is_grad_enabled():
+                self.refresh_wt()       # W^T shadows for the backward's row-form dgrads: off the forward's critical path
+        self._on_side(beside)
         self.ragged_step = self.ragged and plan.ragged_ok
         if self.ragged_step and self.sparse_conv and torch.is_grad_enabled():
             self._conv_rows(plan)       # host-side list building + upload, hidden behind the forward kernels already queued
@@ -879,6 +939,7 @@ class JepaEngine:
         N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, self.G, self.C
         De, Dd = c.d_enc, c.d_dec
         f.g32.zero_()
+        self.refresh_wt()               # (already done beside the forward; a no-op then)
         rag = self.ragged_step
         Md, dseq = (plan.n_dec, (plan.dec_off, max(plan.max_dec, 1))) if rag else (Mp, None)
         Me, eseq = (plan.n_ctx, (plan.enc_off, max(plan.max_enc, 1))) if rag else (M, None)

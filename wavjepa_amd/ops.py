@@ -171,6 +171,17 @@ def gemm_set_variant(variant: int) -> int:
     return int(_abi.load().wj_gemm_set_variant(int(variant)))
 
 
+def transpose_bf16(src: Ptr, dst: Ptr, table: torch.Tensor, n_mats: int, n_tiles: int, stream: Optional[int] = None) -> None:
+    """Batched in-layout transposes: for every row (element offset, rows, cols, first tile) of `table` (int64 [n_mats][4], device):
+    dst[off + c*rows + r] = src[off + r*cols + c]."""
+    _run("wj_transpose_bf16", "wj_transpose_args", stream, src=_p(src), dst=_p(dst), table=_p(table), n_mats=n_mats, n_tiles=n_tiles)
+
+
+def gemm_set_persist_cus(workgroups_per_xcd: int) -> int:
+    """Resident workgroups per XCD of the persistent GEMM (1..32; <= 0 only queries).  Returns the previous value."""
+    return int(_abi.load().wj_gemm_set_persist_cus(int(workgroups_per_xcd)))
+
+
 def pick_split_k(M: int, N: int, K: int) -> int:
     """Split-K factor for the wgrad GEMM: fill the 256 CUs (tile 256 x 256 -> 1 workgroup/CU, 256 x 128 -> 2)."""
     bn = 256 if N % 256 == 0 else 128           # mirrors pick_variant() in csrc/gemm.hip for the ATOMIC (wgrad) epilogue

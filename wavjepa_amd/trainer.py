@@ -62,6 +62,19 @@ def init_distributed() -> tuple:
     return rank, local, world
 
 
+DP_PERSIST_CUS = 28     # resident persistent-GEMM workgroups per XCD in a data-parallel run: 4 CUs per XCD (32 in all) stay free
+
+
+def init_persist_cus(world: int) -> int:
+    """A persistent GEMM workgroup owns its CU (the whole register file, 150 KB of LDS): while one is resident on every CU an RCCL
+    channel kernel cannot start.  With more than one rank the persistent kernels therefore leave DP_PERSIST_CUS..32 CUs per XCD to the
+    gradient all-reduce that runs beside the backward (WJ_PERSIST_CUS set by the user wins).  Returns the value in effect."""
+    from . import ops
+    if world > 1 and "WJ_PERSIST_CUS" not in os.environ:
+        ops.gemm_set_persist_cus(DP_PERSIST_CUS)
+    return ops.gemm_set_persist_cus(0)
+
+
 class StepRunner:
     """One optimisation step in the reference's order."""
 
@@ -73,6 +86,7 @@ class StepRunner:
         if self.reducer.active:
             torch.cuda.synchronize()
             heartbeat("parameters broadcast from rank 0")
+        init_persist_cus(dist.get_world_size() if dist.is_initialized() else 1)
         self._first_step_done = False
         self.sectioned = hasattr(model, "_grads_ready_hook")      # JEPA: bucketed all-reduces launched from the backward's hooks
         if self.sectioned:
