@@ -70,6 +70,26 @@ def masks(golden_dir, n):
     return tuple(torch.from_numpy(fx[k][:n]) for k in ("as_ctx", "as_tgt", "as_vis"))
 
 
+class PinnedRng:
+    """The maskers draw from np.random.default_rng(None) -- OS entropy, as upstream -- on every call: inside this context the k-th
+    default_rng() call returns default_rng(base + k), so that a parity bound is checked on the same masks in every run (with fresh masks
+    per run the noisiest gradient group of the channel-extractor test moved between 1.6 % and 2.6 %)."""
+    def __init__(self, base):
+        self.base, self.k, self.orig = base, 0, np.random.default_rng
+
+    def __call__(self, seed=None):
+        g = self.orig(self.base + self.k)
+        self.k += 1
+        return g
+
+    def __enter__(self):
+        np.random.default_rng = self
+        return self
+
+    def __exit__(self, *a):
+        np.random.default_rng = self.orig
+
+
 def oracle_kw(cfg):
     return dict(spec=cfg["conv_spec"], enc_heads=cfg["h_enc"], dec_heads=cfg["h_dec"], top_k=cfg["top_k"])
 
@@ -411,9 +431,8 @@ def test_full_size_batch_256_clips_equals_its_slices():
     m, _ = build(BASE)
     eng = m._ensure_engine()
     N = 256
-    rng_state = np.random.get_state()
-    ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)(batch_size=N, n_times=200, in_channels=1)
-    np.random.set_state(rng_state)
+    with PinnedRng(2560):
+        ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1)(batch_size=N, n_times=200, in_channels=1)
     audio = torch.randn(N, 1, 32159, device=dev(), generator=torch.Generator(device=dev()).manual_seed(3)).to(torch.bfloat16)
     out = m(audio, ctx, tgt, vis)
     out["loss"].backward()
@@ -493,10 +512,9 @@ def test_forward_backward_parity_channel_extractor(stacks, ragged):
     m, P = build(SMALL, seconds=1.0, tokens=198, in_channels=2, channel_stacks=stacks)
     assert m.total_patches == 198 and m.extract_audio.frames_per_channel(16000) == 99
     m._ensure_engine().ragged = ragged
-    st = np.random.get_state()
-    ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True, channel_major=True)(
-        batch_size=3, n_times=198, in_channels=2)
-    np.random.set_state(st)
+    with PinnedRng(4100):
+        ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True, channel_major=True)(
+            batch_size=3, n_times=198, in_channels=2)
     assert ctx.shape == (3, 198) and torch.equal(ctx[:, :99], ctx[:, 99:])
     audio = torch.from_numpy(synth.synth_audio(3, 2, 16000, seed=31)).to(torch.bfloat16).to(dev())
     out = m(audio, ctx, tgt, vis)
