@@ -52,6 +52,7 @@ class DenoiserEngine(JepaEngine):
             self.dn_ws = torch.empty(ops.workspace_bytes("wj_mse_groups", G=2, n=1) // 4, dtype=torch.float32, device=self.dev)
         self.dn_w.copy_(torch.tensor([alpha, 1.0 - alpha], dtype=torch.float32))
         self.audio, self.plan, self.ragged_step = audio, None, False
+        self.set_wt_need(self.M, 0)
         self.dn_targets = targets.reshape(-1, c.d_enc).float().contiguous()
         self._frontend(audio)
         x, xb = self.lf, self.lf_b

@@ -83,6 +83,26 @@ class MaskPlan:
     ctx_np: Optional[np.ndarray] = None       # host copy of the context mask (True = NOT context), for the conv row lists
 
 
+def pack_upload(arrays: Sequence[np.ndarray], device) -> List[torch.Tensor]:
+    """One host -> device copy for a set of small index / mask arrays (uint8 / int32): packed into one byte buffer at 256-byte offsets,
+    copied once, returned as typed views of the device buffer (every view keeps it alive).  A step builds ~25 such lists (mask plan,
+    sparse-conv row lists); as separate `.to(device)` calls each was its own copy kernel on the stream."""
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 255) // 256 * 256
+    host = np.zeros(max(total, 256), dtype=np.uint8)
+    for a, o in zip(arrays, offs):
+        host[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
+    out = []
+    for a, o in zip(arrays, offs):
+        t = dev_buf[o:o + a.nbytes]
+        out.append(t.view({1: torch.uint8, 4: torch.int32}[a.dtype.itemsize]).reshape(a.shape) if a.nbytes else
+                   torch.zeros(a.shape, dtype={1: torch.uint8, 4: torch.int32}[a.dtype.itemsize], device=device))
+    return out
+
+
 def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
     """Build the plan.  CPU masks (the data-loader case) need no device synchronisation."""
     if isinstance(ctx_mask, torch.Tensor) and ctx_mask.is_cuda:
@@ -120,13 +140,13 @@ def make_mask_plan(ctx_mask, target_indices, vis_mask, device) -> MaskPlan:
     else:
         tgt_rows = tgt_inv = tgt_dense = np.zeros(0, np.int32)
 
-    def up(a, dt):
-        return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device, non_blocking=True)
-
-    return MaskPlan(up(ctx_np, np.uint8), up(tgt_np, np.uint8), up(vis_np, np.uint8), up(keep_np, np.int32), up(inv_np, np.int32),
-                    int(keep_np.size), N=n_clips, G=n_groups, T=n_tok, enc_off=up(enc_off, np.int32), dec_rows=up(dec_rows, np.int32),
-                    dec_off=up(dec_off, np.int32), dec_map=up(dec_map, np.int32), n_dec=int(dec_rows.size),
-                    tgt_rows=up(tgt_rows, np.int32), tgt_inv=up(tgt_inv, np.int32), tgt_dense=up(tgt_dense, np.int32),
+    d = pack_upload([ctx_np.astype(np.uint8), tgt_np.astype(np.uint8), vis_np.astype(np.uint8), keep_np.astype(np.int32),
+                     inv_np.astype(np.int32), enc_off.astype(np.int32), dec_rows.astype(np.int32), dec_off.astype(np.int32),
+                     dec_map.astype(np.int32), tgt_rows.astype(np.int32), tgt_inv.astype(np.int32), tgt_dense.astype(np.int32)], device)
+    return MaskPlan(d[0], d[1], d[2], d[3], d[4],
+                    int(keep_np.size), N=n_clips, G=n_groups, T=n_tok, enc_off=d[5], dec_rows=d[6],
+                    dec_off=d[7], dec_map=d[8], n_dec=int(dec_rows.size),
+                    tgt_rows=d[9], tgt_inv=d[10], tgt_dense=d[11],
                     n_tgt=int(tgt_rows.size),
                     max_enc=int(ctx_len.max()) if ctx_len.size else 0, max_dec=int(dec_len.max()) if dec_len.size else 0,
                     ragged_ok=ragged_ok, ctx_np=ctx_np)
@@ -331,30 +351,34 @@ class JepaEngine:
     def _bind_wt(self) -> None:
         """W^T shadows: one more bf16 buffer with the parameter layout, every 2-D transformer weight stored transposed at its own offset."""
         f = self.flat
-        self._wt_table, self._wt_n, self._wt_tiles, self.p16t = None, 0, 0, None
+        self.p16t = None
+        self._wt_tables = {}                   # (student weights, predictor weights) that take the row form -> (table, n_mats, n_tiles)
+        self._wt_need = ((), ())               # ... of the step being run (set by the forward from its row counts)
         if self.wt_dgrad:
-            rows, tiles = [], 0
-            for w in self.enc_layers + self.dec_layers:
-                for k in ("wqkv", "wo", "w1", "w2"):
-                    s = f.by_name[getattr(w, k + "_name")]
-                    r, cc = s.shape
-                    if r % 64 or cc % 64:
-                        rows = None
-                        break
-                    rows.append((s.offset, r, cc, tiles))
-                    tiles += (r // 64) * (cc // 64)
-                if rows is None:
-                    break
-            if rows:
+            ok = all(r % 64 == 0 and cc % 64 == 0 for w in self.enc_layers + self.dec_layers for k in ("wqkv", "wo", "w1", "w2")
+                     for r, cc in [f.by_name[getattr(w, k + "_name")].shape])
+            if ok:
                 self.p16t = torch.zeros(f.n, dtype=torch.bfloat16, device=self.dev)
-                self._wt_table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
-                self._wt_n, self._wt_tiles = len(rows), tiles
                 for w in self.enc_layers + self.dec_layers:
                     for k in ("wqkv", "wo", "w1", "w2"):
                         setattr(w, k + "T", self.p16t.data_ptr() + 2 * f.by_name[getattr(w, k + "_name")].offset)
             else:
                 self.wt_dgrad = False          # a width that is not a multiple of 64: keep the col-form dgrads
         self._wt_fresh = False
+        self._wt_live = {}
+
+    @staticmethod
+    def _row_form_pays(M: int, N: int) -> bool:
+        """A dgrad [M, N] takes the row form (W^T shadow) only where it fills the persistent kernel: >= 256 work items of 256 rows x
+        256 / 128 columns.  Measured in the step, the student's 117-tile dgrads (M ~ 10 k context rows, N = 768) run 58 / 47 / 20 us in
+        col form on the 256 x 128 schedule (234 workgroups) against 64 / 49 / 24 us in row form on the one-tile eight-phase schedule."""
+        return -(-M // 256) * (N // 256 + (1 if N % 256 else 0)) >= 256
+
+    def _wt_keys(self, M: int, D: int):
+        """The weights of a stack of width D whose dgrad over M rows takes the row form (output widths: w2 -> 4D, the others -> D)."""
+        if not self.wt_dgrad:
+            return ()
+        return tuple(k for k, n_out in (("wqkv", D), ("wo", D), ("w1", D), ("w2", 4 * D)) if self._row_form_pays(M, n_out))
 
     def _alloc_conv_weights(self) -> None:
         C = self.C
@@ -652,20 +676,38 @@ class JepaEngine:
         ops.gemm_mxfp8(q, w8[0], sc, w8[1], out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, ld_scale_a=M, ld_scale_b=N, epilogue=epilogue, C2=C2,
                        bias=bias, **extra)
 
+    def set_wt_need(self, rows_enc: int, rows_dec: int) -> None:
+        """Which weights' dgrads run in row form this step (decided per stack from its row count)."""
+        self._wt_need = (self._wt_keys(rows_enc, self.cfg.d_enc), self._wt_keys(rows_dec, self.cfg.d_dec) if self.dec_layers else ())
+        self._wt_live = {id(w): self._wt_need[0] for w in self.enc_layers}
+        self._wt_live.update({id(w): self._wt_need[1] for w in self.dec_layers})
+
     def refresh_wt(self) -> None:
-        """bf16 W^T shadows from the current bf16 weights (one batched transpose; once per prepared set of weights)."""
-        if self.wt_dgrad and not self._wt_fresh:
-            ops.transpose_bf16(self.flat.p16, self.p16t, self._wt_table, self._wt_n, self._wt_tiles)
-            self._wt_fresh = True
+        """bf16 W^T shadows from the current bf16 weights: one batched transpose of the weights this step's dgrads read in row form
+        (`_wt_need`: with the AudioSet masker at 256 clips all four of every predictor layer and linear2 of every student layer,
+        99 of the 213 MB of transformer weights); once per prepared set of weights."""
+        if not self.wt_dgrad or self._wt_fresh:
+            return
+        need = self._wt_need
+        if need not in self._wt_tables:
+            f, rows, tiles = self.flat, [], 0
+            for layers, keys in ((self.enc_layers, need[0]), (self.dec_layers, need[1])):
+                for w in layers:
+                    for k in keys:
+                        sl = f.by_name[getattr(w, k + "_name")]
+                        r, cc = sl.shape
+                        rows.append((sl.offset, r, cc, tiles))
+                        tiles += (r // 64) * (cc // 64)
+            self._wt_tables[need] = (torch.tensor(rows, dtype=torch.int64, device=self.dev) if rows else None, len(rows), tiles)
+        table, n_mats, n_tiles = self._wt_tables[need]
+        if n_mats:
+            ops.transpose_bf16(self.flat.p16, self.p16t, table, n_mats, n_tiles)
+        self._wt_fresh = True
 
     def _dgrad(self, dY, w: _Layer, key: str, out, *, M: int, N: int, K: int, **kw) -> None:
         """out[M, N] = dY[M, K] . W   (W = the layer's `key` weight, stored [K][N] as nn.Linear keeps it): against the W^T shadow as a
         row-form GEMM, or (WJ_WT_DGRAD=0, widths that are not multiples of 64) against W itself in col form."""
-        # only where the row-form product fills the persistent kernel (>= 256 work items of 256 rows x 256 / 128 columns): measured in
-        # the step, the student's 117-tile dgrads (M ~ 10 k context rows, N = 768) run 58 / 47 / 20 us in col form on the 256 x 128
-        # schedule (234 workgroups) against 64 / 49 / 24 us in row form on the one-tile eight-phase schedule
-        items = -(-M // 256) * (N // 256 + (1 if N % 256 else 0))
-        if self.wt_dgrad and items >= 256:
+        if self.wt_dgrad and key in self._wt_live.get(id(w), ()):
             ops.gemm(dY, getattr(w, key + "T"), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
         else:
             ops.gemm(dY, getattr(w, key), out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, **kw)
@@ -808,6 +850,9 @@ class JepaEngine:
         self._frontend(audio)
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
+        rag_now = self.ragged and plan.ragged_ok
+        self.set_wt_need(plan.n_ctx if rag_now else M, plan.n_dec if rag_now else Mp)
+
         def beside():
             self._teacher_targets()
             if torch.is_grad_enabled():
@@ -1102,16 +1147,30 @@ class JepaEngine:
             keep = np.ascontiguousarray(keep.reshape(N, S, self.Tc).transpose(1, 0, 2)).reshape(S * N, self.Tc)
         lists = conv_active_rows(keep, self.P, self.cfg.conv_spec)
         pad = np.zeros(256, np.int32)        # the k-gather GEMM prefetches indices up to 256 entries past the end
-
-        def up(a):
-            return torch.from_numpy(np.concatenate([a, pad])).to(self.dev, non_blocking=True)
+        # every list of the step in ONE host -> device copy
+        act0, off0 = lists[0]
+        host, keys = [], []
+        for l, (act, ext) in lists.items():
+            if l == 0:
+                continue
+            host += [np.concatenate([act, pad]).astype(np.int32), np.concatenate([ext, pad]).astype(np.int32)]
+            keys += [("act", l), ("ext", l)]
+        per0_host = []
+        for ch in range(S):
+            lo, hi = int(off0[ch * N]), int(off0[(ch + 1) * N])
+            rows = (act0[lo:hi] - ch * N * self.P[0]).astype(np.int32)
+            off = (off0[ch * N:(ch + 1) * N + 1] - lo).astype(np.int32)
+            per0_host.append((rows, off))
+            host += [np.concatenate([rows, pad]).astype(np.int32), np.concatenate([off, pad]).astype(np.int32)]
+            keys += [("rows0", ch), ("off0", ch)]
+        dev = dict(zip(keys, pack_upload(host, self.dev)))
 
         groups = self._stack_groups()
         out = {}
         for l, (act, ext) in lists.items():
             if l == 0:
                 continue
-            d_act, d_ext = up(act), up(ext)
+            d_act, d_ext = dev[("act", l)], dev[("ext", l)]
             per = []
             for _, c0, nclips in groups:
                 lo, hi = c0 * self.P[l], (c0 + nclips) * self.P[l]
@@ -1120,13 +1179,9 @@ class JepaEngine:
                 per.append((d_act.data_ptr() + 4 * int(a0), int(a1 - a0), d_ext.data_ptr() + 4 * int(e0), int(e1 - e0)))
             out[l] = per
             out[("keep", l)] = (d_act, d_ext)        # owners of the pointers above
-        act0, off0 = lists[0]
         per0 = []
-        for ch in range(S):
-            lo, hi = int(off0[ch * N]), int(off0[(ch + 1) * N])
-            rows = (act0[lo:hi] - ch * N * self.P[0]).astype(np.int32)
-            off = (off0[ch * N:(ch + 1) * N + 1] - lo).astype(np.int32)
-            per0.append((up(rows), int(rows.size), up(off), int(np.diff(off).max()) if off.size > 1 else 0))
+        for ch, (rows, off) in enumerate(per0_host):
+            per0.append((dev[("rows0", ch)], int(rows.size), dev[("off0", ch)], int(np.diff(off).max()) if off.size > 1 else 0))
         out[0] = per0
         plan._conv_rows = ((self.N, self.S, len(self.stacks), tuple(self.P)), out)
         return out
