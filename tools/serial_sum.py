@@ -42,11 +42,21 @@ CLASSES = [   # (label, regex on the kernel name); first match wins
 ]
 
 
+OUTLIERS = []
+
+
 def load(path):
     rows = []
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
-            rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"])))
+            calls, total, mx = int(r["Calls"]), float(r["TotalDurationNs"]), float(r.get("MaxNs") or 0)
+            # one launch far outside its kernel's distribution (seen once in nine profiled runs: a single 25-ms launch of a kernel that
+            # averages 0.1 ms -- a box hiccup under the profiler, not a property of the build): reported, and replaced by the mean of
+            # the other launches so that it does not decide an A/B
+            if calls > 8 and mx > 3e6 and mx > 30 * (total - mx) / (calls - 1):
+                OUTLIERS.append((path, r["Name"].split("(")[0][-60:], mx / 1e6))
+                total = (total - mx) * calls / (calls - 1)
+            rows.append((r["Name"], calls, total))
     steps = max([c for n, c, _ in rows if "adamw_kernel" in n] or [1])
     out, kernels = {}, {}
     for name, calls, ns in rows:
@@ -76,6 +86,8 @@ def main():
             y = b.get(label, [0.0, 0])
             line += f" {y[0]:8.3f} {y[0] - x[0]:+7.3f}"
         print(line)
+    for path, name, ms in OUTLIERS:
+        print(f"# outlier dropped in {path}: one launch of {name} took {ms:.1f} ms")
     print("\n# kernels (ms/step, launches/step, us/launch)")
     for k, v in sorted(ka.items(), key=lambda kv: -kv[1][0])[:40]:
         print(f"{k:70s} {v[0]:8.3f} {v[1]:7.1f} {v[2]:9.1f}")
