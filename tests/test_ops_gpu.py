@@ -143,6 +143,89 @@ def test_gemm_persistent_schedule(ops, M, N, K, epi):
             assert relerr(C4.float(), hb * valid) < 4e-3 and relerr(C24.float(), g * valid) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K,cus", [(33100, 384, 384, 32),      # a full + a half-width item per 256-row panel, shifted M edge
+                                        (33100, 640, 256, 32),      # two full tiles + a half-width item
+                                        (40000, 384, 1152, 28),     # fewer resident workgroups per XCD (the data-parallel default)
+                                        (20000, 1152, 128, 5)])     # ... far fewer: every workgroup pulls many items
+def test_gemm_persistent_half_width_items_and_fewer_workgroups(ops, M, N, K, cus):
+    """N % 256 == 128: the last work item of a row panel is 128 columns wide (no duplicated columns).  Through the C ABI on NaN-filled
+    outputs: bit-identical to the one-tile eight-phase kernel up to the bias-first last-place differences, bit-identical to itself
+    across launches and across the number of resident workgroups per XCD (wj_gemm_set_persist_cus)."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=21)
+    W = rnd(N, K, scale=0.08, dtype=torch.bfloat16, seed=22)
+    bias = rnd(N, seed=23)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+
+    def run(variant, n_cus):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        prev_v, prev_c = ops.gemm_set_variant(variant), ops.gemm_set_persist_cus(n_cus)
+        try:
+            ops.gemm(A, W, C, **kw)
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_set_variant(prev_v)
+            ops.gemm_set_persist_cus(prev_c)
+        return C
+
+    C4 = run(4, cus)
+    assert not bool(torch.isnan(C4.float()).any())
+    for n_cus in (cus, 32, 17):
+        assert torch.equal(run(4, n_cus).view(torch.int16), C4.view(torch.int16)), n_cus
+    C3 = run(3, 32)
+    d = (C3.float() - C4.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and bool((d <= 2.0 ** -6 * torch.maximum(C3.float().abs(), C4.float().abs()) + 1e-4).all())
+    assert relerr(C4.float(), A.float() @ W.float().t() + bias) < 4e-3
+    assert ops.gemm_set_persist_cus(0) == 32                 # the process default is untouched
+
+
+@pytest.mark.parametrize("M,N,K", [(33001, 1536, 384), (20000, 640, 256), (9907, 3072, 768)])
+def test_gemm_persistent_mul_gelu_grad_with_column_sums(ops, M, N, K):
+    """The backward through linear2 + GELU as a row-form GEMM against W^T on the persistent kernel (reference: autograd of
+    nn.TransformerEncoderLayer's `linear2(activation(linear1(x)))`, types/wavjepa_configs.py:28-47): C = bf16(bf16(acc) * gelu'(h)), and
+    the column sums of C (linear1's bias gradient) ADDED to what the buffer holds.  Bit-identical to the one-tile schedule; the sums
+    against float64 sums of the stored values; rows that a shifted M-edge tile shares with its neighbour are counted once."""
+    dY = rnd(M, K, dtype=torch.bfloat16, seed=31)
+    Wt = rnd(N, K, scale=0.08, dtype=torch.bfloat16, seed=32)       # W^T: [N][K], K contiguous
+    gp = (torch.rand(M, N, device=dev(), generator=torch.Generator(device=dev()).manual_seed(33)) * 1.2 - 0.1).to(torch.bfloat16)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_MUL_GELU_GRAD, aux=gp)
+    out = {}
+    for v in (3, 4):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        cs = torch.full((N,), 0.5, device=dev())
+        prev = ops.gemm_set_variant(v)
+        try:
+            ops.gemm(dY, Wt, C, colsum=cs, **kw)
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_set_variant(prev)
+        out[v] = (C, cs)
+    assert torch.equal(out[3][0].view(torch.int16), out[4][0].view(torch.int16))
+    C = out[4][0].float()
+    want = 0.5 + C.sum(0, dtype=torch.float64)
+    scale = C.abs().sum(0, dtype=torch.float64) + 1e-6
+    for v in (3, 4):
+        assert float(((out[v][1].double() - want).abs() / scale).max()) < 2e-5, v
+    assert relerr(C, (dY.float() @ Wt.float().t()).to(torch.bfloat16).float() * gp.float()) < 6e-3
+
+
+def test_transpose_bf16_batched(ops):
+    """wj_transpose_bf16: several matrices of one flat buffer transposed in place of their own offsets in a second one (the W^T shadows
+    of the row-form dgrads)."""
+    shapes = [(384, 1152), (1536, 384), (64, 64), (768, 3072)]
+    offs, rows, tiles, total = [], [], 0, 0
+    for r, c in shapes:
+        offs.append(total)
+        rows.append((total, r, c, tiles))
+        tiles += (r // 64) * (c // 64)
+        total += r * c + 8                                   # slots are padded to 8 elements in the flat layout
+    src = rnd(total, dtype=torch.bfloat16, seed=41)
+    dst = torch.full((total,), float("nan"), dtype=torch.bfloat16, device=dev())
+    table = torch.tensor(rows, dtype=torch.int64, device=dev())
+    ops.transpose_bf16(src, dst, table, len(rows), tiles)
+    for (r, c), o in zip(shapes, offs):
+        assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 136, 192), (512, 768, 3072)])
 def test_gemm_dgrad_layout(ops, M, N, K):
     """dX[M, N] = dY[M, K] @ W[K, N]  (b_trans: W stored [K][N], N contiguous)."""
