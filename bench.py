@@ -454,7 +454,7 @@ def main():
     executed_gflop = None
     if not args.no_profile:
         note("instrumented step")
-        classes = optional("instrumented step", lambda: profile_one_step(runner, source, step_idx)) or {}
+        classes = optional("instrumented step", lambda: profile_one_step(runner, source, step_idx), collective=True) or {}   # (a full step: its gradient all-reduce is a collective)
         gemms = {k: v for k, v in classes.items() if v["flops"] > 0}
         executed_gflop = sum(v["flops"] for v in gemms.values()) / 1e9      # GEMM flops one step actually executes
         if gemms:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 11
+#define WJ_ABI_VERSION 12
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -194,7 +194,8 @@ typedef struct {
     float* dbeta;
     float* dbias;
     float* workspace; /* optional f32 [1536][3][D]: per-workgroup partials (plain stores) folded by a second kernel
-                         instead of ~1500 contended atomics per column */
+                         instead of ~1500 contended atomics per column.  With dgamma = dbeta = dbias = NULL the partials are LEFT there
+                         ([wj_ln_bwd_partial_rows(M, D)][3][D]: dgamma | dbeta | dbias) for a later wj_colsum_f32_group */
     int32_t M, D;
     int32_t x_is_bf16;
     int32_t in_seg, in_valid;
@@ -214,6 +215,25 @@ typedef struct {
 int wj_colsum_bf16(const wj_colsum_args*, void* stream);
 /* same for an f32 matrix (x: f32 [M][N], ldx in elements): folds per-workgroup partial sums */
 int wj_colsum_f32(const wj_colsum_args*, void* stream);
+
+/* Deferred folds of parameter-gradient partials: up to WJ_COLSUM_GROUP_MAX matrices in one launch.  Item i: o0/o1/o2[c] += column sums
+ * of x[i] (f32 [M][ldx], N columns; columns [0, n_each) -> o0, [n_each, 2 n_each) -> o1, the rest -> o2; NULL outputs are skipped).
+ * The LayerNorm and attention backward of one transformer layer leave three such matrices (wj_layernorm_bwd with NULL gradient
+ * outputs, wj_attn_bwd with defer_fold): folded per group of layers instead of by 75 launches of ~5 us per step
+ * (autograd of nn.LayerNorm / in_proj_bias inside nn.TransformerEncoderLayer, jepa.py:125-131).  N <= 2304, N <= 3 * n_each. */
+#define WJ_COLSUM_GROUP_MAX 16
+typedef struct {
+    const float* x[WJ_COLSUM_GROUP_MAX];
+    float* o0[WJ_COLSUM_GROUP_MAX];
+    float* o1[WJ_COLSUM_GROUP_MAX];
+    float* o2[WJ_COLSUM_GROUP_MAX];
+    int64_t ldx[WJ_COLSUM_GROUP_MAX];
+    int32_t M[WJ_COLSUM_GROUP_MAX], N[WJ_COLSUM_GROUP_MAX], n_each[WJ_COLSUM_GROUP_MAX];
+    int32_t n;
+} wj_colsum_group_args;
+int wj_colsum_f32_group(const wj_colsum_group_args*, void* stream);
+/* rows of partials wj_layernorm_bwd writes for M token rows of width D (its workgroup count); no stream, no device work */
+int wj_ln_bwd_partial_rows(int M, int D);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-head self-attention with a key-padding mask, forward and backward.
@@ -250,6 +270,7 @@ typedef struct {
     float* dbias_ws;  /* f32 [B][3*H*hd] scratch, required with dbias: per-(b,h) partials, folded by a second kernel */
     int32_t B, T, H, hd;
     int32_t mask_group;
+    int32_t defer_fold; /* 1: leave the partials in dbias_ws (rows = B, width 3*H*hd) for a later wj_colsum_f32_group into dbias */
 } wj_attn_bwd_args;
 int wj_attn_bwd(const wj_attn_bwd_args*, void* stream);
 

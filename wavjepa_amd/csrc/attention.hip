@@ -791,7 +791,7 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     } else {
         hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 14>), grid, dim3(NWB32 * 64), lds, st, *a);
     }
-    if (a->dbias) {
+    if (a->dbias && !a->defer_fold) {
         wj_colsum_args c;
         c.x = a->dbias_ws; c.out = a->dbias; c.ldx = 3L * a->H * a->hd; c.M = a->B; c.N = 3 * a->H * a->hd;
         const int rc = wj_colsum_f32(&c, stream);

@@ -349,6 +349,44 @@ void launch_colsum_f32(const float* x, long ldx, int M, int N, float* o0, float*
     hipLaunchKernelGGL(colsum_f32_kernel, dim3(gx, gy), dim3(256), 0, s, x, ldx, M, N, o0, o1, o2, n_each, rows);
 }
 
+// The same fold for up to WJ_COLSUM_GROUP_MAX matrices in ONE launch: the per-workgroup partials that the LayerNorm / attention backward
+// kernels of a few layers left in their own scratch rows (wj_colsum_f32_group).  An item gets GROUP_CB x GROUP_RB workgroup slots
+// (column blocks of 128 x row ranges); slots beyond its width return at once.
+constexpr int GROUP_CB = 18, GROUP_RB = 8;      // up to 2304 columns (3 x 768), 8 row ranges
+__global__ __launch_bounds__(256) void colsum_f32_group_kernel(wj_colsum_group_args a) {
+    __shared__ float red[8][132];
+    const int item = blockIdx.x / (GROUP_CB * GROUP_RB), rem = blockIdx.x - item * (GROUP_CB * GROUP_RB);
+    const int cb = rem % GROUP_CB, rb = rem / GROUP_CB;
+    const int M = a.M[item], N = a.N[item];
+    if (cb * 128 >= N) return;
+    const float* x = a.x[item];
+    const long ldx = a.ldx[item];
+    int rows = (M + GROUP_RB - 1) / GROUP_RB;
+    rows = (rows + 7) / 8 * 8;
+    const int t = threadIdx.x, cc = t & 31, rl = t >> 5;
+    const int col = cb * 128 + cc * 4;
+    const int r0 = rb * rows, r1 = min(M, r0 + rows);
+    if (r0 >= M) return;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (col < N)
+        for (int r = r0 + rl; r < r1; r += 8) acc += *reinterpret_cast<const f32x4*>(x + (long)r * ldx + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cc * 4 + e] = acc[e];
+    __syncthreads();
+    if (t < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][t];
+        const int c = cb * 128 + t;
+        if (c < N) {
+            const int n_each = a.n_each[item];
+            const int which = c / n_each, cc2 = c - which * n_each;
+            float* o = which == 0 ? a.o0[item] : (which == 1 ? a.o1[item] : a.o2[item]);
+            if (o) atomicAdd(o + cc2, s);
+        }
+    }
+}
+
 // column sums: workgroup = 64 columns x a row range; thread (cc = t&7 -> 8 columns, rl = t>>3 -> row lane of 32)
 __global__ __launch_bounds__(256) void colsum_kernel(wj_colsum_args a, int rows_per_wg) {
     __shared__ float red[32][65];
@@ -408,19 +446,41 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
     return WJ_OK;
 }
 
+// partial rows wj_layernorm_bwd leaves in its workspace ([rows][3][D]) for M token rows of width D: its grid
+static int ln_bwd_grid(int M, int D) {
+    const int nw = BWD_THREADS / 64;
+    const bool half = (D % 128 == 0) && (D % 256 != 0) && D <= 384;
+    const int rpw = half ? 2 : 1;
+    // >= 8 rows per wave (4 passes of its two row slots): with fewer the per-workgroup epilogue (LDS fold, partials store)
+    // dominates -- the ragged student's 10 k rows ran at 1.4 TB/s with one pass per wave
+    int grid = (M + 8 * nw * rpw - 1) / (8 * nw * rpw);
+    return grid > 1536 ? 1536 : grid;
+}
+extern "C" int wj_ln_bwd_partial_rows(int M, int D) {
+    if (M <= 0 || D <= 0) return -1;
+    return ln_bwd_grid(M, D);
+}
+
+extern "C" int wj_colsum_f32_group(const wj_colsum_group_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
+    if (!a || a->n < 1 || a->n > WJ_COLSUM_GROUP_MAX) return WJ_ERR_ARG;
+    for (int x = 0; x < a->n; ++x) {
+        if (!a->x[x] || a->M[x] <= 0 || a->N[x] <= 0 || (a->N[x] & 3) || (a->ldx[x] & 3) || a->n_each[x] <= 0) return WJ_ERR_ARG;
+        if (a->N[x] > GROUP_CB * 128 || a->N[x] > 3 * a->n_each[x]) return WJ_ERR_ARG;
+    }
+    hipLaunchKernelGGL(colsum_f32_group_kernel, dim3(a->n * GROUP_CB * GROUP_RB), dim3(256), 0, (hipStream_t)stream, *a);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
 extern "C" int wj_layernorm_bwd(const wj_ln_bwd_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->dy || !a->x || !a->gamma || !a->mean || !a->rstd) return WJ_ERR_ARG;
     if (a->M <= 0 || a->D <= 0 || (a->D & 3) || a->D > 256 * MAXV) return WJ_ERR_ARG;
     if ((a->in_seg > 0 && a->in_valid <= 0) || (a->out_seg > 0 && a->out_valid <= 0)) return WJ_ERR_ARG;
     if (a->chan > 1 && ((a->in_seg > 0 && a->M % (a->chan * a->in_valid)) || (a->out_seg > 0 && a->M % (a->chan * a->out_valid)))) return WJ_ERR_ARG;
-    const int nw = BWD_THREADS / 64;
     const bool half = (a->D % 128 == 0) && (a->D % 256 != 0) && a->D <= 384;
-    const int rpw = half ? 2 : 1;
-    // >= 8 rows per wave (4 passes of its two row slots): with fewer the per-workgroup epilogue (LDS fold, partials store)
-    // dominates -- the ragged student's 10 k rows ran at 1.4 TB/s with one pass per wave
-    int grid = (a->M + 8 * nw * rpw - 1) / (8 * nw * rpw);
-    if (grid > 1536) grid = 1536;
+    const int grid = ln_bwd_grid(a->M, a->D);
     dim3 g(grid), b(BWD_THREADS);
     hipStream_t s = (hipStream_t)stream;
     if (half) {

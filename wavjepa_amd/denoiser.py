@@ -82,6 +82,7 @@ class DenoiserEngine(JepaEngine):
                                          i % bw["nbuf"], None, flush=(c.l_enc - 1 - i) % bw["group"] == bw["group"] - 1 or i == 0,
                                          bottom=i == 0)
         self._frontend_bwd(dy, False, None)
+        self._flush_folds()
         self._join_side()
         bw["used"] = [False] * bw["nbuf"]
 

@@ -290,6 +290,10 @@ class JepaEngine:
         # batched transpose, wj_transpose_bf16): the persistent eight-phase kernel instead of the col-form 256 x 128 schedule.
         # WJ_WT_DGRAD=0 keeps the col-form dgrads (A/B runs).
         self.wt_dgrad = _os.environ.get("WJ_WT_DGRAD", "1") != "0"
+        self._conv_w_fresh = False
+        self.early_frontend = _os.environ.get("WJ_EARLY_FRONTEND", "1") != "0"
+        self.defer_folds = _os.environ.get("WJ_DEFER_FOLDS", "1") != "0"
+        self._folds = []
         self._bind_params()
         self._bind_wt()
         self._conv_w: Dict[str, torch.Tensor] = {}
@@ -438,7 +442,15 @@ class JepaEngine:
         if self.fp8:
             self._fp8_weights()
         self._wt_fresh = False                      # the shadows follow p16; refreshed by the first backward that needs them
-        C = self.C
+        self._conv_w_fresh = False                  # GEMM layouts of conv layers 1..: rebuilt by the front-end, behind its conv0 launches
+
+    def _conv_weight_layouts(self) -> None:
+        """GEMM layouts of conv layers 1.. from the fp32 masters (20 launches of ~5 us).  Issued by the front-end AFTER the conv0 kernels
+        are queued: at the start of a step the GPU is idle, and the host needs ~15 us per launch -- behind conv0 (1.1 ms) they cost nothing,
+        in front of it they were 0.3 ms of idle GPU per step (rocprofv3 trace, tools/trace_gaps.py)."""
+        if self._conv_w_fresh:
+            return
+        f, C = self.flat, self.C
         for si, pre in enumerate(self.stacks):
             for l, (_, k, s) in enumerate(self.cfg.conv_spec):
                 if l == 0:
@@ -449,6 +461,7 @@ class JepaEngine:
                     U = len(range(rho, k, s))
                     if U > 0:
                         ops.conv_weight_layout(src, self._conv_w[f"{si}:wd{l}_{rho}"], C_out=C, C_in=C, k=k, mode=1, stride=s, rho=rho, U=U)
+        self._conv_w_fresh = True
 
     # ------------------------------------------------------------------------------------------------ arena
     def _rows(self, nrows: int, width: int, dtype, lead: int = 2, tail: int = 8) -> Tuple[torch.Tensor, int]:
@@ -497,7 +510,7 @@ class JepaEngine:
         need_dec = min(need_dec or full_dec, full_dec)
         same = N == self.N and (not train or (getattr(self, "_train_alloc", False) and G == self.G))
         if same and (not train or (need_enc <= self.cap_enc and need_dec <= self.cap_dec)):
-            return
+            return False
         margin = float(os.environ.get("WJ_ARENA_MARGIN", "1.15"))
 
         def cap(need: int, full: int, old: int) -> int:
@@ -561,7 +574,7 @@ class JepaEngine:
         self.enc_fm = _empty(M, dtype=f32, device=dev)
         self.enc_fr = _empty(M, dtype=f32, device=dev)
         if not train:
-            return
+            return True
         self.enc_acts = self._alloc_stack(Me, c.d_enc, c.h_enc, N, c.l_enc)
         self.dec_acts = self._alloc_stack(Md, c.d_dec, c.h_dec, N * G, c.l_dec)
         self.ctx_in = _empty(Me, c.d_enc, dtype=bf, device=dev)      # gathered context rows (<= Me)
@@ -604,11 +617,17 @@ class JepaEngine:
                         ops.workspace_bytes("wj_attn_bwd", B=N * G, H=c.h_dec, hd=c.d_dec // c.h_dec),
                         ops.workspace_bytes("wj_attn_bwd", B=N, H=c.h_enc, hd=c.d_enc // c.h_enc))
         self.red_ws = _empty(red_bytes // 4, dtype=f32, device=dev)
+        # deferred folds (WJ_DEFER_FOLDS=0: every LayerNorm / attention backward folds its own partials at once, 75 launches of ~5 us
+        # per step): each pending producer keeps its partial rows in its own slot until one grouped launch folds up to 16 of them
+        self._red_bytes = (red_bytes + 255) // 256 * 256
+        self.fold_ws = _empty(ops.COLSUM_GROUP_MAX * self._red_bytes // 4, dtype=f32, device=dev)
+        self._folds = []
         self.dpreds = _empty(Md, c.d_enc, dtype=bf, device=dev)
         self.d_cf = _empty(Me, c.d_dec, dtype=bf, device=dev)
         self.d_ctx_in = _empty(Me, c.d_enc, dtype=bf, device=dev)
         self.d_lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         self.d_fn = _empty(M, C, dtype=f32, device=dev)
+        return True
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
@@ -712,6 +731,37 @@ class JepaEngine:
         else:
             ops.gemm(dY, getattr(w, key), out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, **kw)
 
+    # ---- parameter-gradient folds of the LayerNorm / attention backward, deferred and grouped
+    def _fold_slot(self) -> int:
+        if len(self._folds) >= ops.COLSUM_GROUP_MAX:
+            self._flush_folds()
+        return self.fold_ws.data_ptr() + len(self._folds) * self._red_bytes
+
+    def _flush_folds(self) -> None:
+        """One launch adds the column sums of every pending partial matrix to its gradient slices (stream-ordered behind the
+        kernels that wrote them; called before a section of the gradient buffer is declared final)."""
+        if self._folds:
+            ops.colsum_f32_group(self._folds)
+            self._folds = []
+
+    def _ln_bwd(self, dy, x, gamma, mean, rstd, *, M: int, D: int, dgamma=None, dbeta=None, dbias=None, **kw) -> None:
+        """wj_layernorm_bwd; its dgamma / dbeta / dbias partials are folded later, together with the neighbours' (see _flush_folds)."""
+        if self.defer_folds and 3 * D <= 2304 and (dgamma or dbeta or dbias):
+            ws = self._fold_slot()
+            ops.layernorm_bwd(dy, x, gamma, mean, rstd, M=M, D=D, workspace=ws, **kw)
+            self._folds.append((ws, 3 * D, ops.ln_bwd_partial_rows(M, D), 3 * D, dgamma, dbeta, dbias, D))
+        else:
+            ops.layernorm_bwd(dy, x, gamma, mean, rstd, M=M, D=D, dgamma=dgamma, dbeta=dbeta, dbias=dbias, workspace=self.red_ws, **kw)
+
+    def _attn_bwd(self, qkv, out, dout, lse, dqkv, *, B: int, H: int, hd: int, dbias, **kw) -> None:
+        D3 = 3 * H * hd
+        if self.defer_folds and D3 <= 2304 and dbias:
+            ws = self._fold_slot()
+            ops.attn_bwd(qkv, out, dout, lse, dqkv, B=B, H=H, hd=hd, dbias=dbias, dbias_ws=ws, defer_fold=True, **kw)
+            self._folds.append((ws, D3, B, D3, dbias, None, None, D3))
+        else:
+            ops.attn_bwd(qkv, out, dout, lse, dqkv, B=B, H=H, hd=hd, dbias=dbias, dbias_ws=self.red_ws, **kw)
+
     def _wgrad(self, dY, X, gW, n_out: int, k_in: int, m_tok: int) -> None:
         """gW[n_out, k_in] += dY[m_tok, n_out]^T @ X[m_tok, k_in]"""
         ops.gemm(dY, X, gW, M=n_out, N=k_in, K=m_tok, lda=n_out, ldb=k_in, ldc=k_in, a_trans=1, b_trans=1,
@@ -758,15 +808,15 @@ class JepaEngine:
             M = sub[2]
             x_ln1, o_in = self.tail_x, self.tail_o
         dgb, dxb = bw["dgb"], bw["dxb"]
-        ops.layernorm_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, dy2=dyb, dy2_is_bf16=dyb is not None, ds_f32=ds, ds_bf16=dsb2,
-                          dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2, workspace=self.red_ws)
+        self._ln_bwd(dy, a.x1, w.g2, a.m2, a.r2, M=M, D=D, r=a.f, dy2=dyb, dy2_is_bf16=dyb is not None, ds_f32=ds, ds_bf16=dsb2,
+                     dgamma=w.gg2, dbeta=w.gbe2, dbias=w.gb2)
         self._dgrad(dsb2, w, "w2", dh, M=M, N=4 * D, K=D, epilogue=ops.EPI_MUL_GELU_GRAD, aux=a.h,
                     colsum=w.gb1)        # linear1.bias gradient = column sums of dh, fused into the producing epilogue
 
         bw["pending"] += [(dsb2, a.g, w.gw2, D, 4 * D, M), (dh, a.x1b, w.gw1, 4 * D, D, M)]
         self._dgrad(dh, w, "w1", dgb, M=M, N=D, K=4 * D)
-        ops.layernorm_bwd(ds, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, dy2=dgb, dy2_is_bf16=True, ds_f32=ds, ds_bf16=dsb1,
-                          dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo, workspace=self.red_ws)      # ds updated in place
+        self._ln_bwd(ds, x_ln1, w.g1, a.m1, a.r1, M=M, D=D, r=a.p, dy2=dgb, dy2_is_bf16=True, ds_f32=ds, ds_bf16=dsb1,
+                     dgamma=w.gg1, dbeta=w.gbe1, dbias=w.gbo)      # ds updated in place
         ds_all = ds
         if sub is None:
             self._dgrad(dsb1, w, "wo", do, M=M, N=D, K=D)
@@ -776,9 +826,9 @@ class JepaEngine:
             ops.unmask_rows_f32(ds, sub[1], dx1, M=Mall, D=D, src_is_f32=True)       # dx1 is free again: residual gradient
             ds_all = dx1
         if seq is not None:
-            ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], dbias=w.gbqkv, dbias_ws=self.red_ws)
+            self._attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=seq[1], H=H, hd=D // H, seq_off=seq[0], dbias=w.gbqkv)
         else:
-            ops.attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv, dbias_ws=self.red_ws)
+            self._attn_bwd(a.qkv, a.o, do, a.lse, dqkv, B=B, T=self.T, H=H, hd=D // H, key_mask=mask, dbias=w.gbqkv)
 
         bw["pending"] += [(dsb1, o_in, w.gwo, D, D, M), (dqkv, xb_in, w.gwqkv, 3 * D, D, Mall)]
         bw["pending_slots"].append(parity)
@@ -816,6 +866,7 @@ class JepaEngine:
                           self.gn_ws, N=N, C_in=c.in_channels, L=c.n_samples, C=C, k=k0, stride=s0, L_out=self.L[0], P=self.P[0],
                           yx=self.gn_yx[c0:] if grad else None, x1=self.gn_x1[c0:] if grad else None,
                           audio_clip_stride=S * c.in_channels * c.n_samples if S > 1 else 0)
+        self._conv_weight_layouts()
         for l in range(1, len(c.conv_spec)):
             _, k, s = c.conv_spec[l]
             for si, c0, nclips in self._stack_groups():
@@ -835,26 +886,45 @@ class JepaEngine:
         ops.add_pos(src, self.pos_enc, M=M, T=T, D=c.d_enc, y_f32=self.lf, y_bf16=self.lf_b)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, audio: torch.Tensor, plan: MaskPlan) -> None:
-        """Training forward.  Results: self.loss[0], self.preds, self.targets, self.cf[:n_ctx], self.lf."""
+    def begin_forward(self, audio: torch.Tensor) -> bool:
+        """The part of the training forward that needs no masks -- conv front-end, then the teacher on the side stream -- queued BEFORE
+        the host builds the mask plan (index lists of 256 x 4 x 200 masks: ~0.5 ms of NumPy during which the GPU, drained by the
+        previous step's optimiser, sat idle: rocprofv3 trace, 0.46 ms per step).  Only when the arena already fits this batch size;
+        returns whether it ran.  forward() repeats the work if its row counts then force a larger arena."""
+        N = audio.shape[0]
+        if not (self.early_frontend and N == self.N and getattr(self, "_train_alloc", False)):
+            return False
+        self.audio = audio
+        self._frontend(audio)
+        self._on_side(self._teacher_targets)
+        return True
+
+    def forward(self, audio: torch.Tensor, plan: MaskPlan, begun: bool = False) -> None:
+        """Training forward.  Results: self.loss[0], self.preds, self.targets, self.cf[:n_ctx], self.lf.
+        begun: begin_forward(audio) already queued the front-end and the teacher for this batch."""
         c, f = self.cfg, self.flat
         N = audio.shape[0]
         if plan.N != N or plan.T != self.T or plan.G < 1:
             raise ValueError(f"mask plan is for {plan.N} clips x {plan.G} groups x {plan.T} tokens; the batch has {N} clips of {self.T} tokens")
         rag = self.ragged and plan.ragged_ok
-        self.alloc(N, train=True, G=plan.G, need_enc=plan.n_ctx if rag else 0, need_dec=plan.n_dec if rag else 0)
+        rebuilt = self.alloc(N, train=True, G=plan.G, need_enc=plan.n_ctx if rag else 0, need_dec=plan.n_dec if rag else 0)
         self.plan = plan
         self.audio = audio
         M, Mp, T, G = self.M, self.Mp, self.T, self.G
         De, Dd = c.d_enc, c.d_dec
-        self._frontend(audio)
+        if rebuilt and begun:
+            self._join_side()           # the early teacher wrote into the arena that was just replaced: let it finish, then start over
+            begun = False
+        if not begun:
+            self._frontend(audio)
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
         rag_now = self.ragged and plan.ragged_ok
         self.set_wt_need(plan.n_ctx if rag_now else M, plan.n_dec if rag_now else Mp)
 
         def beside():
-            self._teacher_targets()
+            if not begun:
+                self._teacher_targets()
             if torch.is_grad_enabled():
                 self.refresh_wt()       # W^T shadows for the backward's row-form dgrads: off the forward's critical path
         self._on_side(beside)
@@ -980,6 +1050,11 @@ class JepaEngine:
             ready = lambda tag: self._on_side(lambda: on_grads_ready(tag))
         else:
             ready = on_grads_ready
+        section_final = ready
+
+        def ready(tag):                  # a section is final only once the pending parameter-gradient folds have been queued
+            self._flush_folds()
+            section_final(tag)
         c, f, plan = self.cfg, self.flat, self.plan
         N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, self.G, self.C
         De, Dd = c.d_enc, c.d_dec
@@ -1037,6 +1112,7 @@ class JepaEngine:
                         enc_ready.add(j)
                         ready(f"enc:{j}")
         self._frontend_bwd(dy, rag, plan)
+        self._flush_folds()
         self._join_side()                # all weight gradients are final before the optimiser / last all-reduce
         for tag in ("enc", "dec"):
             self.bw[tag]["used"] = [False] * self.bw[tag]["nbuf"]

@@ -437,9 +437,11 @@ class JEPA(_ModuleBase):
             raise ValueError(f"expected {self.target_length} samples per clip, got {audio.shape[-1]}")
         if audio.shape[1] != self.extract_audio.in_channels:
             raise ValueError(f"expected {self.extract_audio.in_channels} audio channel(s), got {audio.shape[1]}")
-        plan = ctx_masks if isinstance(ctx_masks, MaskPlan) else make_mask_plan(ctx_masks, target_indices, ctx_and_target_masks, self.device)
         self._prepare_weights()
-        eng.forward(audio, plan)
+        # the mask-free part of the forward (conv front-end, teacher) goes to the GPU before the host builds the index lists
+        begun = torch.is_grad_enabled() and eng.begin_forward(audio)
+        plan = ctx_masks if isinstance(ctx_masks, MaskPlan) else make_mask_plan(ctx_masks, target_indices, ctx_and_target_masks, self.device)
+        eng.forward(audio, plan, begun=begun)
         N, T = audio.shape[0], eng.T
         if torch.is_grad_enabled():
             loss = _EngineLoss.apply(self._anchor, self)

@@ -23,6 +23,7 @@ EPI_ATOMIC_F32 = ENUMS["WJ_EPI_ATOMIC_F32"]
 EPI_CONV_GELU = ENUMS["WJ_EPI_CONV_GELU"]
 EPI_BIAS_GELU = ENUMS["WJ_EPI_BIAS_GELU"]
 GROUP_STATS_SPLIT = _abi.DEFINES["WJ_GROUP_STATS_SPLIT"]
+COLSUM_GROUP_MAX = _abi.DEFINES["WJ_COLSUM_GROUP_MAX"]
 
 
 def _p(x: Ptr) -> int:
@@ -212,6 +213,29 @@ def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, 
          out_valid=out_valid, chan=chan)
 
 
+def ln_bwd_partial_rows(M: int, D: int) -> int:
+    """Rows of partials layernorm_bwd leaves in its workspace ([rows][3][D]) for M token rows of width D."""
+    return int(_abi.load().wj_ln_bwd_partial_rows(int(M), int(D)))
+
+
+def colsum_f32_group(items, stream: Optional[int] = None) -> None:
+    """items: [(x, ldx, M, N, o0, o1, o2, n_each)] (<= 16): one launch folds every matrix's column sums into its outputs (+=)."""
+    a = STRUCTS["wj_colsum_group_args"]()
+    for i, (x, ldx, M, N, o0, o1, o2, n_each) in enumerate(items):
+        a.x[i], a.o0[i], a.o1[i], a.o2[i] = _p(x), _p(o0), _p(o1), _p(o2)
+        a.ldx[i], a.M[i], a.N[i], a.n_each[i] = ldx, M, N, n_each
+    a.n = len(items)
+    s = _stream() if stream is None else stream
+    if PROFILE is None:
+        _abi.call("wj_colsum_f32_group", a, s)
+        return
+    e0, e1 = TimingEvent(), TimingEvent()
+    e0.record(s)
+    _abi.call("wj_colsum_f32_group", a, s)
+    e1.record(s)
+    PROFILE.append(("wj_colsum_f32_group", dict(n=len(items)), e0, e1))
+
+
 def colsum_bf16(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[int] = None) -> None:
     _run("wj_colsum_bf16", "wj_colsum_args", stream, x=_p(x), out=_p(out), ldx=ldx, M=M, N=N)
 
@@ -229,10 +253,11 @@ def attn_fwd(qkv: Ptr, out: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: P
 
 
 def attn_bwd(qkv: Ptr, out: Ptr, dout: Ptr, lse: Ptr, dqkv: Ptr, *, B: int, T: int, H: int, hd: int, key_mask: Ptr = None,
-             mask_group: int = 1, dbias: Ptr = None, dbias_ws: Ptr = None, seq_off: Ptr = None,
+             mask_group: int = 1, dbias: Ptr = None, dbias_ws: Ptr = None, seq_off: Ptr = None, defer_fold: bool = False,
              stream: Optional[int] = None) -> None:
     _run("wj_attn_bwd", "wj_attn_bwd_args", stream, qkv=_p(qkv), key_mask=_p(key_mask), seq_off=_p(seq_off), out=_p(out), dout=_p(dout),
-         lse=_p(lse), dqkv=_p(dqkv), dbias=_p(dbias), dbias_ws=_p(dbias_ws), B=B, T=T, H=H, hd=hd, mask_group=mask_group)
+         lse=_p(lse), dqkv=_p(dqkv), dbias=_p(dbias), dbias_ws=_p(dbias_ws), B=B, T=T, H=H, hd=hd, mask_group=mask_group,
+         defer_fold=int(defer_fold))
 
 
 # ---------------------------------------------------------------------------------------------------------- conv front-end
