@@ -83,18 +83,59 @@ class MaskPlan:
     ctx_np: Optional[np.ndarray] = None       # host copy of the context mask (True = NOT context), for the conv row lists
 
 
+class _PinnedStaging:
+    """A small ring of page-locked host buffers for the per-step index uploads.  A copy from PAGEABLE memory is staged by the runtime
+    and holds the host until everything queued on the stream before it has run (seen in the rocprofv3 trace as 0.2 ms of idle GPU
+    between the crop kernel and the first front-end kernel of every step, and as a 1.7 ms longer one-stream step when the upload was
+    issued behind the queued teacher forward); from page-locked memory it is just one more stream operation.  A buffer is reused only
+    after the event recorded behind its last copy has completed."""
+    RING = 6
+
+    def __init__(self):
+        self.slots = []            # [tensor (uint8, pinned), event or None]
+        self.next = 0
+
+    def get(self, nbytes: int):
+        if len(self.slots) < self.RING:
+            self.slots.append([torch.empty(max(nbytes * 3 // 2, 1 << 20), dtype=torch.uint8, pin_memory=True), None])
+            return self.slots[-1]
+        slot = self.slots[self.next % self.RING]
+        self.next += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0].numel() < nbytes:
+            slot[0] = torch.empty(nbytes * 3 // 2, dtype=torch.uint8, pin_memory=True)
+        return slot
+
+
+_STAGING = _PinnedStaging()
+_PINNED_UPLOADS = __import__("os").environ.get("WJ_PINNED_UPLOAD", "1") != "0"     # 0: pageable staging (A/B runs)
+
+
 def pack_upload(arrays: Sequence[np.ndarray], device) -> List[torch.Tensor]:
     """One host -> device copy for a set of small index / mask arrays (uint8 / int32): packed into one byte buffer at 256-byte offsets,
-    copied once, returned as typed views of the device buffer (every view keeps it alive).  A step builds ~25 such lists (mask plan,
-    sparse-conv row lists); as separate `.to(device)` calls each was its own copy kernel on the stream."""
+    copied once (from page-locked staging memory when the target is a GPU), returned as typed views of the device buffer (every view
+    keeps it alive).  A step builds ~25 such lists (mask plan, sparse-conv row lists); as separate `.to(device)` calls each was its own
+    copy kernel on the stream."""
     offs, total = [], 0
     for a in arrays:
         offs.append(total)
         total += (a.nbytes + 255) // 256 * 256
-    host = np.zeros(max(total, 256), dtype=np.uint8)
+    total = max(total, 256)
+    on_gpu = torch.device(device).type == "cuda" and _PINNED_UPLOADS
+    if on_gpu:
+        slot = _STAGING.get(total)
+        host = slot[0].numpy()[:total]
+    else:
+        host = np.zeros(total, dtype=np.uint8)
     for a, o in zip(arrays, offs):
         host[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-    dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
+    if on_gpu:
+        dev_buf = slot[0][:total].to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
+    else:
+        dev_buf = torch.from_numpy(host).to(device, non_blocking=True)
     out = []
     for a, o in zip(arrays, offs):
         t = dev_buf[o:o + a.nbytes]
@@ -291,7 +332,6 @@ class JepaEngine:
         # WJ_WT_DGRAD=0 keeps the col-form dgrads (A/B runs).
         self.wt_dgrad = _os.environ.get("WJ_WT_DGRAD", "1") != "0"
         self._conv_w_fresh = False
-        self.early_frontend = _os.environ.get("WJ_EARLY_FRONTEND", "1") != "0"
         self.defer_folds = _os.environ.get("WJ_DEFER_FOLDS", "1") != "0"
         self._folds = []
         self._bind_params()
@@ -886,45 +926,26 @@ class JepaEngine:
         ops.add_pos(src, self.pos_enc, M=M, T=T, D=c.d_enc, y_f32=self.lf, y_bf16=self.lf_b)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def begin_forward(self, audio: torch.Tensor) -> bool:
-        """The part of the training forward that needs no masks -- conv front-end, then the teacher on the side stream -- queued BEFORE
-        the host builds the mask plan (index lists of 256 x 4 x 200 masks: ~0.5 ms of NumPy during which the GPU, drained by the
-        previous step's optimiser, sat idle: rocprofv3 trace, 0.46 ms per step).  Only when the arena already fits this batch size;
-        returns whether it ran.  forward() repeats the work if its row counts then force a larger arena."""
-        N = audio.shape[0]
-        if not (self.early_frontend and N == self.N and getattr(self, "_train_alloc", False)):
-            return False
-        self.audio = audio
-        self._frontend(audio)
-        self._on_side(self._teacher_targets)
-        return True
-
-    def forward(self, audio: torch.Tensor, plan: MaskPlan, begun: bool = False) -> None:
-        """Training forward.  Results: self.loss[0], self.preds, self.targets, self.cf[:n_ctx], self.lf.
-        begun: begin_forward(audio) already queued the front-end and the teacher for this batch."""
+    def forward(self, audio: torch.Tensor, plan: MaskPlan) -> None:
+        """Training forward.  Results: self.loss[0], self.preds, self.targets, self.cf[:n_ctx], self.lf."""
         c, f = self.cfg, self.flat
         N = audio.shape[0]
         if plan.N != N or plan.T != self.T or plan.G < 1:
             raise ValueError(f"mask plan is for {plan.N} clips x {plan.G} groups x {plan.T} tokens; the batch has {N} clips of {self.T} tokens")
         rag = self.ragged and plan.ragged_ok
-        rebuilt = self.alloc(N, train=True, G=plan.G, need_enc=plan.n_ctx if rag else 0, need_dec=plan.n_dec if rag else 0)
+        self.alloc(N, train=True, G=plan.G, need_enc=plan.n_ctx if rag else 0, need_dec=plan.n_dec if rag else 0)
         self.plan = plan
         self.audio = audio
         M, Mp, T, G = self.M, self.Mp, self.T, self.G
         De, Dd = c.d_enc, c.d_dec
-        if rebuilt and begun:
-            self._join_side()           # the early teacher wrote into the arena that was just replaced: let it finish, then start over
-            begun = False
-        if not begun:
-            self._frontend(audio)
+        self._frontend(audio)
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
         rag_now = self.ragged and plan.ragged_ok
         self.set_wt_need(plan.n_ctx if rag_now else M, plan.n_dec if rag_now else Mp)
 
         def beside():
-            if not begun:
-                self._teacher_targets()
+            self._teacher_targets()
             if torch.is_grad_enabled():
                 self.refresh_wt()       # W^T shadows for the backward's row-form dgrads: off the forward's critical path
         self._on_side(beside)

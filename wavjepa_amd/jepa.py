@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .engine import EngineConfig, JepaEngine, MaskPlan, make_mask_plan
+from .engine import EngineConfig, JepaEngine, MaskPlan, make_mask_plan, pack_upload
 from .extractors.audio_extractor import Extractor
 from .functions import trunc_normal_
 from .params import FlatParams
@@ -416,8 +416,11 @@ class JEPA(_ModuleBase):
         perm_inv = torch.empty_like(idx)
         perm_inv[idx] = torch.arange(B * S)
         out = torch.empty(B * S, C, self.target_length, dtype=torch.bfloat16, device=self.device)
+        # (through the page-locked staging ring: a copy from pageable memory would hold the host until the previous step's optimiser
+        # kernels have run)
+        perm_dev = pack_upload([perm_inv.to(torch.int32).numpy()], self.device)[0]
         ops.crop_normalize_bf16(audio_batch, starts.to(torch.int32), out, B=B, S=S, C=C, L_full=L_full, length=self.target_length,
-                                perm_inv=perm_inv.to(torch.int32).to(self.device, non_blocking=True))
+                                perm_inv=perm_dev)
         return out, self.collate_fn(ctx_masks), self.collate_fn(target_indices), self.collate_fn(ctx_and_target_masks)
 
     # ------------------------------------------------------------------------------------------------ step
@@ -437,11 +440,9 @@ class JEPA(_ModuleBase):
             raise ValueError(f"expected {self.target_length} samples per clip, got {audio.shape[-1]}")
         if audio.shape[1] != self.extract_audio.in_channels:
             raise ValueError(f"expected {self.extract_audio.in_channels} audio channel(s), got {audio.shape[1]}")
-        self._prepare_weights()
-        # the mask-free part of the forward (conv front-end, teacher) goes to the GPU before the host builds the index lists
-        begun = torch.is_grad_enabled() and eng.begin_forward(audio)
         plan = ctx_masks if isinstance(ctx_masks, MaskPlan) else make_mask_plan(ctx_masks, target_indices, ctx_and_target_masks, self.device)
-        eng.forward(audio, plan, begun=begun)
+        self._prepare_weights()
+        eng.forward(audio, plan)
         N, T = audio.shape[0], eng.T
         if torch.is_grad_enabled():
             loss = _EngineLoss.apply(self._anchor, self)
