@@ -950,6 +950,11 @@ class JepaEngine:
                 self.refresh_wt()       # W^T shadows for the backward's row-form dgrads: off the forward's critical path
         self._on_side(beside)
         self.ragged_step = self.ragged and plan.ragged_ok
+        if self.ragged_step and self.sparse_conv and torch.is_grad_enabled():
+            # host-side list building + upload, hidden behind the forward kernels already queued.  (Building the lists later, behind
+            # the student / predictor launches, measured the same outside the profiler -- 48.89 against 48.79 ms over three runs each --
+            # and opened a 2-ms gap under rocprofv3, whose per-launch overhead makes the host the slower side.)
+            self._conv_rows(plan)
         n_ctx = plan.n_ctx
         if self.ragged_step:
             # student encoder on the context rows only, packed per clip (non-context rows are dropped at jepa.py:399 and,
@@ -1000,11 +1005,6 @@ class JepaEngine:
                           y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr)
         ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Mo, N=De, K=Dd, lda=Dd, ldb=Dd,
                  ldc=De, bias=f.ptr32("decoder_to_encoder_mapper.bias"))
-        if self.ragged_step and self.sparse_conv and torch.is_grad_enabled():
-            # host-side row lists of the sparse conv backward (~10 ms of NumPy for 256 clips) + their upload: built HERE, with the whole
-            # student / predictor forward already queued -- built right behind the front-end (as until round 4) they kept the main
-            # stream empty for those 10 ms while only the teacher ran on the side stream
-            self._conv_rows(plan)
         self._join_side()               # teacher targets (side stream) are needed by the loss
         self._mse(None, None)
 
