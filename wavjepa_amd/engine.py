@@ -550,7 +550,7 @@ class JepaEngine:
         need_dec = min(need_dec or full_dec, full_dec)
         same = N == self.N and (not train or (getattr(self, "_train_alloc", False) and G == self.G))
         if same and (not train or (need_enc <= self.cap_enc and need_dec <= self.cap_dec)):
-            return False
+            return
         margin = float(os.environ.get("WJ_ARENA_MARGIN", "1.15"))
 
         def cap(need: int, full: int, old: int) -> int:
@@ -614,7 +614,7 @@ class JepaEngine:
         self.enc_fm = _empty(M, dtype=f32, device=dev)
         self.enc_fr = _empty(M, dtype=f32, device=dev)
         if not train:
-            return True
+            return
         self.enc_acts = self._alloc_stack(Me, c.d_enc, c.h_enc, N, c.l_enc)
         self.dec_acts = self._alloc_stack(Md, c.d_dec, c.h_dec, N * G, c.l_dec)
         self.ctx_in = _empty(Me, c.d_enc, dtype=bf, device=dev)      # gathered context rows (<= Me)
@@ -667,7 +667,6 @@ class JepaEngine:
         self.d_ctx_in = _empty(Me, c.d_enc, dtype=bf, device=dev)
         self.d_lf_b = _empty(M, c.d_enc, dtype=bf, device=dev)
         self.d_fn = _empty(M, C, dtype=f32, device=dev)
-        return True
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _layer_fwd(self, w: _Layer, a: _Acts, x_in: torch.Tensor, xb_in: torch.Tensor, M: int, D: int, H: int, B: int,
