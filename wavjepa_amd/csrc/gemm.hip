@@ -1103,7 +1103,8 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 //   1 = 256x256 tile, plain schedule     : split-K wgrad (long K loop; 850-1000 TFLOP/s)
 //   2 = 256x256 tile, ping-pong schedule : forward / conv shapes with plain epilogues and K >= 512 (+9..17 % over variant 0)
 //   3 = 256x256x64 tile, eight-phase     : row-form operands, K % 128 == 0 (+10..15 % over variant 2 at K = 768, +35 % at 8192^3)
-//   4 = variant 3's loop, persistent     : >= 256 output tiles, forward epilogues (csrc/gemm_persist.hip)
+//   4 = variant 3's loop, persistent     : >= 256 work items; forward epilogues, plain BF16 and MUL_GELU_GRAD (+ column sums) for the
+//                                          row-form dgrads against W^T shadows (csrc/gemm_persist.hip)
 // WJ_GEMM_VARIANT=0|1|2|3 (or wj_gemm_set_variant) forces one (A/B runs; 1-3 need N % 256 == 0 to avoid wasted columns but
 // stay correct; a variant that cannot run a shape falls back to 0).
 int g_forced_variant = -2;   // -2: not initialised (WJ_GEMM_VARIANT decides), -1: automatic, >= 0: forced

@@ -1,5 +1,6 @@
 // Persistent form of the eight-phase bf16 GEMM (variant 4 of wj_gemm_bf16): C[M,N] = A[M,K] . B[N,K]^T, row-form operands,
-// K % 128 == 0, M >= 256, N >= 256, forward epilogues (bias / erf-GELU / conv GELU).
+// K % 128 == 0, M >= 256, N >= 256; epilogues: bias / erf-GELU / conv GELU (forward) and, since round 4, x gelu'(h) with the column sums
+// of the result (the backward through linear2 + GELU; the predictor's other dgrads are plain BF16 launches against W^T shadows).
 //
 // Why.  In the one-tile-per-workgroup kernels (csrc/gemm.hip) a 256 x 256 tile with K = 768 spends half of its life outside the
 // MFMA loop: the first operand pieces travel with nothing to hide them, the C tile goes accumulators -> LDS -> global between two
@@ -21,7 +22,9 @@
 //     than the pieces those waits retire); by the end of the second K tile they have drained;
 //   * edge tiles are SHIFTED, not clipped: the last tile row / column starts at M - 256 / N - 256 and recomputes a strip its
 //     neighbour also writes (same operands, same k order: the same bits).  No clamped rows, no predicated stores, every tile issues
-//     the same instruction stream -- which is what lets the vmcnt arithmetic above count on the stores;
+//     the same instruction stream -- which is what lets the vmcnt arithmetic above count on the stores.  Round 4: when N % 256 == 128
+//     the last item of a row panel is a HALF-WIDTH one instead (columns [N - 128, N), the B1 quadrants' MFMA clusters skipped): a
+//     shifted tile there recomputed and rewrote a third (N = 384) of the launch's columns;
 //   * tiles are PULLED: a workgroup's first tile is static (block id), every further one comes from an atomic counter of its XCD
 //     label (blockIdx % 8: the tiles of one A panel stay on one L2), fetched a whole tile ahead by lane 0 of wave 0 and passed to the
 //     other waves through an LDS word.  Workgroups that start late (a second stream holds their CU) simply pull fewer tiles.  Every
