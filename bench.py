@@ -509,6 +509,9 @@ def main():
                        "token_execution": "ragged" if model._engine.ragged else "dense",
                        # resident workgroups per XCD of the persistent GEMM (32 = every CU; N > 1 leaves CUs to the RCCL kernels)
                        "persistent_gemm_workgroups_per_xcd": persist_cus,
+                       # who carries the gradient buckets: torch.distributed (backend nccl = RCCL) or, WJ_RCCL_DIRECT=1, the library's
+                       # own RCCL binding (include/wavjepa_hip.h wj_rccl_bucket_allreduce_*); None without a process group
+                       "gradient_transport": None if not runner.reducer.active else ("wj_rccl_bucket_allreduce" if runner.reducer.direct else "torch.distributed"),
                        "step_gflop_per_clip_dense": STEP_GFLOP_PER_CLIP,
                        "step_gemm_gflop_per_clip_executed": None if executed_gflop is None else round(executed_gflop / args.clips_per_gpu, 1)},
             # executed GEMM flops (instrumented step) over the measured step time; NOT the dense-shape flop count

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 12
+#define WJ_ABI_VERSION 13
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -544,6 +544,32 @@ typedef struct {
     int32_t n_mats, n_tiles;
 } wj_transpose_args;
 int wj_transpose_bf16(const wj_transpose_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gradient-bucket all-reduce over RCCL (reference train.py:174-179: Lightning strategy="ddp" = NCCL bucket averages).
+ * One communicator per process (= per GPU).  wj_rccl_unique_id on ONE rank -> its 128 bytes to every rank over any side channel ->
+ * wj_rccl_bucket_allreduce_init on every rank (collective, blocks until all ranks called it) -> per bucket _launch on a stream ->
+ * _wait makes the consuming stream wait for the bucket stream.  RCCL is resolved at run time (the copy already loaded in the
+ * process, else librccl.so): WJ_ERR_UNSUPPORTED (-3) without it or before init.  The package's default transport remains
+ * torch.distributed (backend "nccl" is this same RCCL); WJ_RCCL_DIRECT=1 routes the gradient buckets through these entries.
+ * -----------------------------------------------------------------------------------------------------------*/
+typedef struct {
+    const void* unique_id; /* 128 bytes from wj_rccl_unique_id (HOST memory) */
+    int32_t rank, world;
+} wj_rccl_init_args;
+typedef struct {
+    float* buf;            /* device, contiguous f32: reduced in place */
+    int64_t count;
+    int32_t average;       /* 1: mean over the ranks (DDP semantics), 0: sum */
+} wj_rccl_launch_args;
+typedef struct {
+    void* on_stream;       /* the stream the buckets were launched on */
+} wj_rccl_wait_args;
+int wj_rccl_unique_id(void* out128);
+int wj_rccl_bucket_allreduce_init(const wj_rccl_init_args*);
+int wj_rccl_bucket_allreduce_launch(const wj_rccl_launch_args*, void* stream);
+int wj_rccl_bucket_allreduce_wait(const wj_rccl_wait_args*, void* stream);
+int wj_rccl_bucket_allreduce_finalize(void);
 
 /* dst_bf16[i] = bf16(src_f32[i]) */
 typedef struct {

@@ -56,6 +56,28 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.wj_attn_fwd(ctypes.byref(b), None) == -3               # unsupported head dim
 
 
+def test_rccl_bucket_family_validates_arguments_and_order_without_a_gpu():
+    """SURVEY 8(b) rccl_bucket_allreduce_{init,launch,wait}: argument and ordering errors are answered before RCCL is touched."""
+    from wavjepa_amd import _abi
+    lib = _abi.load()
+    assert lib.wj_rccl_unique_id(None) == -1
+    assert lib.wj_rccl_bucket_allreduce_init(None) == -1
+    ini = _abi.STRUCTS["wj_rccl_init_args"]()
+    assert lib.wj_rccl_bucket_allreduce_init(ctypes.addressof(ini)) == -1          # no id, world 0
+    idbuf = ctypes.create_string_buffer(128)
+    ini.unique_id, ini.rank, ini.world = ctypes.cast(idbuf, ctypes.c_void_p).value, 2, 2
+    assert lib.wj_rccl_bucket_allreduce_init(ctypes.addressof(ini)) == -1          # rank outside the world
+    la = _abi.STRUCTS["wj_rccl_launch_args"]()
+    assert lib.wj_rccl_bucket_allreduce_launch(ctypes.byref(la), None) == -1       # null bucket
+    la.buf, la.count, la.average = 256, 1024, 1
+    assert lib.wj_rccl_bucket_allreduce_launch(ctypes.byref(la), None) == -3       # no communicator yet: refused, nothing launched
+    assert lib.wj_rccl_bucket_allreduce_wait(None, None) == -1
+    assert lib.wj_rccl_bucket_allreduce_finalize() == 0                            # idempotent
+    from wavjepa_amd import ops
+    with pytest.raises(ValueError):
+        ops.rccl_bucket_allreduce_init(b"short", 0, 1)
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

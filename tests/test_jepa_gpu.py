@@ -473,6 +473,26 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
     assert line["config"]["global_batch"] == 16
 
 
+def test_bench_one_rank_gradient_buckets_through_the_librarys_rccl_binding():
+    """WJ_RCCL_DIRECT=1: the buckets leave through wj_rccl_bucket_allreduce_{launch,wait} (own communicator, own stream) instead
+    of torch.distributed.  One rank: the average is the identity, so the run must land on the default transport's loss."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for direct in ("0", "1"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(launch.free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+               "--clips-per-gpu", "16", "--dense-steps", "0", "--no-cpu-baseline", "--no-profile"]
+        rc, out, err = launch.run(cmd, cwd=root, env=dict(os.environ, WJ_RCCL_DIRECT=direct), timeout=300)
+        assert rc == 0, err[-4000:]
+        lines[direct] = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    a, b = lines["0"], lines["1"]
+    assert b["replicas_equal"] is True and b["config"]["gradient_transport"] == "wj_rccl_bucket_allreduce" and a["config"]["gradient_transport"] == "torch.distributed"
+    assert b["allreduce"] is not None and b["allreduce"]["buckets"] >= 2 and b["allreduce"]["exposed_ms"] >= 0
+    assert abs(a["final_loss"] - b["final_loss"]) < 2e-3 * abs(a["final_loss"]), (a["final_loss"], b["final_loss"])
+
+
 def test_bench_two_ranks_share_the_gpu_over_gloo():
     """The N = 2 launch of the bench end to end on the 1-GPU box: RCCL refuses two ranks on one device, so the collectives go over
     gloo (WJ_DIST_BACKEND, a development switch of init_distributed); everything else -- per-rank sources, broadcast, bucketed

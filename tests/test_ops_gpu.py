@@ -965,3 +965,51 @@ def test_crop_normalize(ops, golden_dir):
     want = torch.from_numpy(fx["out_bits"]).view(torch.bfloat16).to(dev())     # the REFERENCE's output bits
     diff = (out.float() - want.float()).abs()
     assert float(diff.max()) <= 2 ** -6 and float((diff > 0).float().mean()) < 2e-3
+
+
+def test_rccl_bucket_allreduce_family_one_rank_world():
+    """wj_rccl_unique_id -> _init -> _launch (average / sum, on a side stream) -> _wait -> _finalize through the C ABI on a world of one
+    (the box has one GPU and RCCL takes one rank per device): reduced values equal the inputs bit for bit, the consuming stream is
+    ordered behind the bucket stream, and a second init without finalize is refused.  In a child process: a communicator is
+    per-process state."""
+    import os
+    import sys
+    import launch
+    code = r'''
+import torch
+from wavjepa_amd import ops, _abi
+dev = torch.device("cuda", 0)
+uid = ops.rccl_unique_id()
+assert len(uid) == 128 and any(uid)
+ops.rccl_bucket_allreduce_init(uid, 0, 1)
+try:
+    ops.rccl_bucket_allreduce_init(uid, 0, 1)
+    raise SystemExit("second init must be refused")
+except _abi.WavJepaHipError:
+    pass
+g = torch.Generator(device="cpu").manual_seed(5)
+x = torch.randn(3_000_000, generator=g).to(dev)
+want = x.clone()
+side = torch.cuda.Stream()
+big = torch.randn(4096, 4096, device=dev)
+for _ in range(20):
+    big = big @ big * 1e-2                     # keep the compute stream busy: the bucket must wait for the producer below
+x.mul_(2.0)
+side.wait_stream(torch.cuda.current_stream())
+ops.rccl_bucket_allreduce_launch(x.data_ptr(), x.numel(), average=True, stream=side.cuda_stream)
+ops.rccl_bucket_allreduce_launch(x[1024:2048].data_ptr(), 1024, average=False, stream=side.cuda_stream)
+ops.rccl_bucket_allreduce_wait(side.cuda_stream)
+y = x * 0.5                                    # current stream: ordered behind both buckets
+torch.cuda.synchronize()
+assert torch.equal(y, want), float((y - want).abs().max())
+ops.rccl_bucket_allreduce_finalize()
+try:
+    ops.rccl_bucket_allreduce_launch(x.data_ptr(), 16)
+    raise SystemExit("launch after finalize must be refused")
+except _abi.WavJepaHipError:
+    pass
+print("RCCL_FAMILY_OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc, out, err = launch.run([sys.executable, "-c", code], cwd=root, timeout=240)
+    assert rc == 0 and "RCCL_FAMILY_OK" in out, (out[-2000:], err[-4000:])

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwavjepa_hip.so")
-SOURCES = ["gemm.hip", "gemm_persist.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip"]
+SOURCES = ["gemm.hip", "gemm_persist.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip", "rccl_bucket.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 

@@ -552,7 +552,7 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
     WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args) WJ_SZ(wj_spin_args)
-    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args) WJ_SZ(wj_colsum_group_args)
+    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args) WJ_SZ(wj_colsum_group_args) WJ_SZ(wj_rccl_init_args) WJ_SZ(wj_rccl_launch_args) WJ_SZ(wj_rccl_wait_args)
 #undef WJ_SZ
     return -1;
 }
@@ -583,7 +583,7 @@ extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     static const char* const none[] = {"wj_gemm_bf16", "wj_layernorm_fwd", "wj_colsum_bf16", "wj_colsum_f32", "wj_attn_fwd", "wj_gelu_bwd_bf16",
         "wj_conv_weight_layout", "wj_add_pos", "wj_mask_gather_rows", "wj_mask_scatter_fill_pos", "wj_mask_scatter_fill_pos_bwd",
         "wj_unmask_rows_f32", "wj_instnorm_accumulate", "wj_instnorm_mean", "wj_ema_update", "wj_adamw_step", "wj_cast_f32_to_bf16",
-        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir", "wj_transpose_bf16", "wj_colsum_f32_group"};
+        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir", "wj_transpose_bf16", "wj_colsum_f32_group", "wj_rccl_bucket_allreduce_launch", "wj_rccl_bucket_allreduce_wait"};
     for (const char* n : none)
         if (!strcmp(fn, n)) return 0;
     return -1;

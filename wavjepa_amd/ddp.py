@@ -8,6 +8,7 @@ or 25 MB autograd buckets: xGMI is point-to-point (7 links/GPU), so fewer, large
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch.distributed as dist
@@ -47,6 +48,10 @@ def section_ranges(flat: FlatParams, enc_layers: int, enc_chunk: int = 3) -> Dic
     return out
 
 
+def process_group_backend(pg=None) -> str:
+    return str(dist.get_backend(pg)).lower()
+
+
 class FlatGradAllReducer:
     def __init__(self, module, process_group=None, enc_chunk: int = 3):
         self.module = module
@@ -64,6 +69,32 @@ class FlatGradAllReducer:
         self.timing = False
         self.timeline: List[Tuple] = []
         self._t_first = None
+        # WJ_RCCL_DIRECT=1: the gradient buckets go through the library's own RCCL binding (wj_rccl_bucket_allreduce_*, the C-ABI
+        # family a host without torch.distributed would use) on a communication stream of their own; the process group then only
+        # carries the 128-byte communicator id and the start-up broadcasts.  Same averages, same bucket order.
+        self.direct = self.active and os.environ.get("WJ_RCCL_DIRECT", "0") == "1"
+        self._comm_stream = None
+        if self.direct:
+            self._init_direct()
+
+    def _init_direct(self) -> None:
+        import torch
+        from . import ops
+        if process_group_backend(self.pg) != "nccl":
+            raise RuntimeError("WJ_RCCL_DIRECT=1 needs one GPU per rank (backend nccl): RCCL refuses two ranks on one device")
+        rank = dist.get_rank(self.pg)
+        box = [ops.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=self.pg)
+        ops.rccl_bucket_allreduce_init(box[0], rank, self.world)
+        self._comm_stream = torch.cuda.Stream()
+
+    def _direct_launch(self, view) -> None:
+        """Bucket `view` (contiguous fp32 slice of the flat gradient buffer) averaged in place on the communication stream, ordered
+        behind everything the compute stream has queued so far (the kernels that produced it)."""
+        import torch
+        from . import ops
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        ops.rccl_bucket_allreduce_launch(view.data_ptr(), view.numel(), average=True, stream=self._comm_stream.cuda_stream)
 
     def broadcast_parameters(self) -> None:
         """Rank 0's student, teacher and optimiser-visible state to everyone (DDP constructor broadcast)."""
@@ -86,7 +117,9 @@ class FlatGradAllReducer:
 
     def reduce_all(self) -> None:
         """One average over the whole flat gradient buffer (modules whose backward exposes no section hooks: the denoiser stage)."""
-        if self.active:
+        if self.direct:
+            self._direct_launch(self.module._flat.g32)
+        elif self.active:
             self.handles.append(dist.all_reduce(self.module._flat.g32, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
 
     def hook(self, tag: str) -> None:
@@ -100,16 +133,22 @@ class FlatGradAllReducer:
             self._t_first = torch.cuda.Event(enable_timing=True)
             self._t_first.record()
         for lo, hi in self._ranges.get(tag, []):
-            self.handles.append(dist.all_reduce(flat.g32[lo:hi], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+            if self.direct:
+                self._direct_launch(flat.g32[lo:hi])
+            else:
+                self.handles.append(dist.all_reduce(flat.g32[lo:hi], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
 
     def wait(self) -> None:
         t_end = t_done = None
-        if self.timing and self.handles:
+        if self.timing and (self.handles or self.direct):
             import torch
             t_end, t_done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t_end.record()
         for h in self.handles:
             h.wait()          # stream-level dependency; does not block the host
+        if self.direct:
+            from . import ops
+            ops.rccl_bucket_allreduce_wait(self._comm_stream.cuda_stream)
         if t_done is not None:
             t_done.record()
             self.timeline.append((self._t_first, t_end, t_done))

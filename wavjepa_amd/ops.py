@@ -236,6 +236,41 @@ def colsum_f32_group(items, stream: Optional[int] = None) -> None:
     PROFILE.append(("wj_colsum_f32_group", dict(n=len(items)), e0, e1))
 
 
+def rccl_unique_id() -> bytes:
+    """128 opaque bytes naming a new RCCL communicator (make on ONE rank, hand to every rank's rccl_bucket_allreduce_init)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    rc = _abi.load().wj_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+    if rc != 0:
+        raise _abi.WavJepaHipError(f"wj_rccl_unique_id failed with {rc}" + (" (no librccl.so in the process or on the library path)" if rc == -3 else ""))
+    return buf.raw
+
+
+def rccl_bucket_allreduce_init(unique_id: bytes, rank: int, world: int) -> None:
+    """Collective: returns once every rank of `world` has called it with the same id."""
+    import ctypes
+    if len(unique_id) != 128:
+        raise ValueError("an RCCL unique id is 128 bytes")
+    buf = ctypes.create_string_buffer(unique_id, 128)
+    a = STRUCTS["wj_rccl_init_args"](unique_id=ctypes.cast(buf, ctypes.c_void_p).value, rank=rank, world=world)
+    rc = _abi.load().wj_rccl_bucket_allreduce_init(ctypes.addressof(a))
+    if rc != 0:
+        raise _abi.WavJepaHipError(f"wj_rccl_bucket_allreduce_init(rank {rank} of {world}) failed with {rc}")
+
+
+def rccl_bucket_allreduce_launch(buf: Ptr, count: int, *, average: bool = True, stream: Optional[int] = None) -> None:
+    _run("wj_rccl_bucket_allreduce_launch", "wj_rccl_launch_args", stream, buf=_p(buf), count=count, average=int(average))
+
+
+def rccl_bucket_allreduce_wait(on_stream: int, stream: Optional[int] = None) -> None:
+    """The stream (default: current) waits for what `on_stream` has queued; the host does not."""
+    _run("wj_rccl_bucket_allreduce_wait", "wj_rccl_wait_args", stream, on_stream=on_stream)
+
+
+def rccl_bucket_allreduce_finalize() -> None:
+    _abi.load().wj_rccl_bucket_allreduce_finalize()
+
+
 def colsum_bf16(x: Ptr, out: Ptr, *, M: int, N: int, ldx: int, stream: Optional[int] = None) -> None:
     _run("wj_colsum_bf16", "wj_colsum_args", stream, x=_p(x), out=_p(out), ldx=ldx, M=M, N=N)
 
