@@ -447,13 +447,25 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
 }
 
 // partial rows wj_layernorm_bwd leaves in its workspace ([rows][3][D]) for M token rows of width D: its grid
+static int ln_bwd_one_pass_rows() {   // WJ_LN_BWD_ONE_PASS_ROWS: launches of at most this many row slots give every wave ONE pass (0 = never)
+    static const int v = [] {
+        const char* e = getenv("WJ_LN_BWD_ONE_PASS_ROWS");
+        return e ? atoi(e) : 16384;
+    }();
+    return v;
+}
 static int ln_bwd_grid(int M, int D) {
     const int nw = BWD_THREADS / 64;
     const bool half = (D % 128 == 0) && (D % 256 != 0) && D <= 384;
     const int rpw = half ? 2 : 1;
-    // >= 8 rows per wave (4 passes of its two row slots): with fewer the per-workgroup epilogue (LDS fold, partials store)
-    // dominates -- the ragged student's 10 k rows ran at 1.4 TB/s with one pass per wave
-    int grid = (M + 8 * nw * rpw - 1) / (8 * nw * rpw);
+    // Large M: >= 8 rows per wave (4 passes of its two row slots) -- the per-workgroup epilogue (LDS fold, partials store) is paid once
+    // per 32 rows and the chip is full anyway.  Small M (the ragged student's 10 k rows are 39 rows per CU): 314 such workgroups put
+    // five waves on a CU, each running its four load -> reduce -> store round trips one after the other (51 us for 139 MB cold); with ONE
+    // pass per wave there are 1256 workgroups, three resident per CU (155 VGPRs), and the launch takes 36 us (tools/ln_bench.py; 6 / 8
+    // / 12-wave workgroups of one pass: 53 / 44 / 36 us -- what counts is how many waves of 155 VGPRs a CU holds, 12, and that they do
+    // not all sit in the same phase).
+    const int passes = (half ? (M + 1) / 2 : M) <= ln_bwd_one_pass_rows() ? 1 : 4;
+    int grid = (M + 2 * passes * nw * rpw - 1) / (2 * passes * nw * rpw);
     return grid > 1536 ? 1536 : grid;
 }
 extern "C" int wj_ln_bwd_partial_rows(int M, int D) {
