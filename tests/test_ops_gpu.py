@@ -671,7 +671,7 @@ def test_fp8_outputs_fused_into_layernorm_and_gelu_epilogue(ops):
 
 
 # ------------------------------------------------------------------------------------------------------------ conv0
-@pytest.mark.parametrize("N,C_in,L,C", [(2, 1, 32159, 512), (3, 1, 4000, 32), (2, 2, 4000, 64)])
+@pytest.mark.parametrize("N,C_in,L,C", [(2, 1, 32159, 512), (3, 1, 4000, 32), (2, 2, 4000, 64), (2, 2, 4100, 128), (3, 1, 2571, 256)])
 def test_conv0_fwd_bwd(ops, N, C_in, L, C):
     k, s = 10, 5
     L_out = (L - k) // s + 1

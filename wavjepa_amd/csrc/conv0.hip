@@ -285,6 +285,109 @@ __global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restri
     }
 }
 
+// ---- pass 2 on the matrix cores (C % 64 == 0, taps <= 32): the VALU form above spends 10 of its ~25 issue slots per output on the
+//      convolution itself; here the conv is one K = 32 MFMA per 16 steps x 16 channels (as in the statistics pass, so both passes now
+//      round the same fp32 sums to bf16) and the vector unit only normalises, applies the erf-GELU and packs.
+//   mfma(P, Q): lane (i, g) gets sum_k Q[row i][k] P[row 4g+r][k];  P = weights, Q = audio patches  -> lane: time step i, and for
+//   channel tile u the four P rows 4g .. 4g+3.  The P rows of tiles 2p, 2p+1 are ASSIGNED to channels so that a lane ends with eight
+//   consecutive channels of one time step: row (4g'+r) of tile u  <->  channel 32 (u >> 1) + 8 g' + 4 (u & 1) + r.  A lane then
+//   writes 16 B, the four lanes of a time step 64 contiguous bytes; a wave owns 64 channels (4 tiles, 2 such stores per 16 steps), a workgroup of eight waves 512.
+//   GroupNorm is applied in its folded form z = y * (rstd gamma) + (beta - mean rstd gamma) (two constants per channel instead of four:
+//   a lane serves 16 channels).
+constexpr int TCA = 512;  // output time steps per workgroup of the MFMA form
+template <int TAPS>
+__global__ __launch_bounds__(512) void conv0_apply_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ sums, bf16_t* __restrict__ act,
+                                                               float* __restrict__ mean_o, float* __restrict__ rstd_o, Geo g, int span,
+                                                               float eps) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t xa[];   // [C_in][span] samples of this chunk (0 past the clip)
+    const int n = blockIdx.y, t0 = blockIdx.x * TCA;
+    for (int ci = 0; ci < g.C_in; ++ci)
+        for (int i = threadIdx.x; i < span; i += 512) {
+            const long src = (long)t0 * g.stride + i;
+            xa[ci * span + i] = src < g.L ? audio[(long)n * g.clip_stride + (long)ci * g.L + src] : f2bf(0.f);
+        }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, gq = lane >> 4;
+    const int tmax = min(TCA, g.P - t0);            // rows this workgroup writes (rows >= L_out are zero padding)
+    const int tlive = min(TCA, g.L_out - t0);       // rows that carry a conv output
+    const float invL = 1.0f / (float)g.L_out;
+    const bf16_t zero = f2bf(0.f);
+    int offc[8];
+    bool okc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = 8 * gq + j, ci = q / g.k;
+        okc[j] = q < TAPS;
+        offc[j] = ci * span + (q - ci * g.k);
+    }
+    for (int cb = wave * 64; cb < g.C; cb += 512) {        // eight waves: 64 channels (four tiles) each
+        bf16x8 wf[4];
+        float ka[4][4], kb[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int crow = cb + 32 * (u >> 1) + 8 * (i >> 2) + 4 * (u & 1) + (i & 3);     // channel of P row i of tile u
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[u][j] = okc[j] ? wsrc[(long)crow * TAPS + 8 * gq + j] : zero;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = cb + 32 * (u >> 1) + 8 * gq + 4 * (u & 1) + r;                // channel of this lane's output r of tile u
+                const float s1 = sums[((long)n * g.C + c) * 2], s2 = sums[((long)n * g.C + c) * 2 + 1];
+                const float mu = s1 * invL;
+                const float var = fmaxf(s2 * invL - mu * mu, 0.f);
+                const float rs = rsqrtf(var + eps);
+                ka[u][r] = rs * gamma[c];
+                kb[u][r] = fmaf(-mu, ka[u][r], beta[c]);
+                if (blockIdx.x == 0 && i == 0) {
+                    mean_o[(long)n * g.C + c] = mu;
+                    rstd_o[(long)n * g.C + c] = rs;
+                }
+            }
+        }
+        auto patch = [&](int t) {
+            bf16x8 pf;
+            const bool live = t < tlive;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (live && okc[j]) ? xa[offc[j] + t * g.stride] : zero;
+            return pf;
+        };
+        bf16x8 pf = patch(i);
+        for (int tb = 0; tb < tmax; tb += 16) {
+            const int t = tb + i;
+            const bool live = t < tlive;
+            const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], pf, z4, 0, 0, 0);   // all four in flight
+            pf = patch(t + 16);                                     // the next block's patches travel from LDS meanwhile
+            bf16_t* dst = act + ((long)n * g.P + t0 + t) * g.C + cb + 8 * gq;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 za, zb, ga, gb, unused;
+                    // the conv output is a bf16 tensor in the reference's autocast flow
+                    za.x = fmaf(bf2f(f2bf(d[2 * p][r])), ka[2 * p][r], kb[2 * p][r]);
+                    za.y = fmaf(bf2f(f2bf(d[2 * p][r + 1])), ka[2 * p][r + 1], kb[2 * p][r + 1]);
+                    zb.x = fmaf(bf2f(f2bf(d[2 * p + 1][r])), ka[2 * p + 1][r], kb[2 * p + 1][r]);
+                    zb.y = fmaf(bf2f(f2bf(d[2 * p + 1][r + 1])), ka[2 * p + 1][r + 1], kb[2 * p + 1][r + 1]);
+                    gelu_pk<false>(za, ga, unused);
+                    gelu_pk<false>(zb, gb, unused);
+                    o[r] = f2bf(ga.x); o[r + 1] = f2bf(ga.y);
+                    o[4 + r] = f2bf(gb.x); o[4 + r + 1] = f2bf(gb.y);
+                }
+                if (!live) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = zero;
+                }
+                if (t < tmax) *reinterpret_cast<bf16x8*>(dst + 32 * p) = o;
+            }
+        }
+    }
+}
+
 // ---- backward, pass over the listed rows: A1 = sum dz, A2 = sum dz xh, S[q] = sum dz x_q  per (n, c) ------------------
 // Every workgroup = (chunk of BR listed rows, clip) STORES its partial part[n][chunk][C][2 + TAPS]; conv0_fold_kernel adds a
 // clip's chunks in order (no float atomics).  rows == NULL: every row t < L_out of every clip.
@@ -434,6 +537,14 @@ void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStrea
                        (const bf16_t*)a->audio, (const bf16_t*)a->w, part, want_yx, g, span);
     hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
                        sums, 2L * a->C, a->yx, (long)a->C * TAPS, a->x1, (const int32_t*)nullptr, 1);
+    static const int use_mfma = [] { const char* e = getenv("WJ_CONV0_APPLY_MFMA"); return e ? atoi(e) : 1; }();   // 0: the VALU form (A/B runs)
+    if (use_mfma && a->C % 64 == 0 && TAPS <= 32) {
+        const int span_a = (TCA - 1) * a->stride + a->k;
+        hipLaunchKernelGGL(conv0_apply_mfma_kernel<TAPS>, dim3((a->P + TCA - 1) / TCA, a->N), dim3(512), (size_t)a->C_in * span_a * sizeof(bf16_t),
+                           s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean,
+                           a->rstd, g, span_a, a->eps);
+        return;
+    }
     hipLaunchKernelGGL(conv0_apply_kernel<TAPS>, grid2, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
                        a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean, a->rstd, g, span_max, a->eps);
 }
