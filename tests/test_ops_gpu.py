@@ -361,7 +361,10 @@ def test_gemm_conv_overlapping_rows(ops):
 
 
 # ------------------------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("M,D", [(37, 768), (64, 384), (67, 384), (10, 32), (9, 512), (5, 1024), (11, 128)])
+# the last four: both grids of the backward (one pass per wave up to 16 384 row slots, four passes and a capped grid beyond) on either
+# side of the switch, for the one-row-per-wave (D = 768) and the two-rows-per-wave (D = 384) forms
+@pytest.mark.parametrize("M,D", [(37, 768), (64, 384), (67, 384), (10, 32), (9, 512), (5, 1024), (11, 128),
+                                 (16384, 768), (16391, 768), (32768, 384), (60003, 384)])
 def test_layernorm_fwd_bwd(ops, M, D):
     x = rnd(M, D, seed=20)
     r = rnd(M, D, dtype=torch.bfloat16, seed=21)
@@ -392,11 +395,12 @@ def test_layernorm_fwd_bwd(ops, M, D):
     wsp = torch.empty(1536 * 3 * D, device=dev())
     ops.layernorm_bwd(dy, x, gamma, mean, rstd, M=M, D=D, r=r, ds_f32=ds, ds_bf16=dsb, dgamma=dg2, dbeta=db2, dbias=dbi2, workspace=wsp)
     assert relerr(dg2, dgamma) < 1e-5 and relerr(db2, dbeta) < 1e-5 and relerr(dbi2, dbias) < 1e-5
+    assert ops.ln_bwd_partial_rows(M, D) <= 1536                     # what the workspace above is sized for
     assert relerr(ds, xr.grad) < 2e-5
-    assert relerr(dgamma, g2.grad) < 2e-5
-    assert relerr(dbeta, b2.grad) < 2e-5
+    assert relerr(dgamma, g2.grad) < (2e-5 if M < 1000 else 2e-4)     # fp32 column sums over up to 60 k rows against torch's
+    assert relerr(dbeta, b2.grad) < (2e-5 if M < 1000 else 2e-4)
     assert torch.equal(dsb, ds.to(torch.bfloat16))
-    assert relerr(dbias, dsb.float().sum(0)) < 1e-5
+    assert relerr(dbias, dsb.float().sum(0)) < (1e-5 if M < 1000 else 2e-4)
 
 
 def test_layernorm_bf16_input_with_row_remap(ops):
