@@ -265,7 +265,9 @@ def test_gemm_wgrad_layout(ops, Mtok, Nout, Kin, split):
 
 
 @pytest.mark.parametrize("dims,K", [([(384, 128), (128, 128), (512, 128), (128, 512)], 1000), ([(192, 64), (64, 64), (256, 64), (64, 256)] * 2, 777),
-                                    ([(2304, 768), (768, 768)], 2500)])
+                                    ([(2304, 768), (768, 768)], 2500),
+                                    # a predictor layer (every shape has a 384: half-full row tiles of the 256 x 128 schedule) and a 72-row tail
+                                    ([(1152, 384), (384, 384), (1536, 384), (384, 1536), (328, 256)], 9000)])
 def test_wgrad_grouped(ops, dims, K):
     """Several dW = dY^T X problems in one launch (one split-K factor for the group) == the individual fp32 products, accumulated
     on top of what the gradient buffers already hold."""
