@@ -1019,3 +1019,49 @@ print("RCCL_FAMILY_OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rc, out, err = launch.run([sys.executable, "-c", code], cwd=root, timeout=240)
     assert rc == 0 and "RCCL_FAMILY_OK" in out, (out[-2000:], err[-4000:])
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_gelu_epilogue_on_every_bf16_input(ops, variant):
+    """nn.GELU() on a bf16 tensor has 65 536 possible inputs: push every one of them through the BIAS_GELU2 epilogue (h = bf16(0 + bias),
+    A = 0) of each GEMM schedule and hold gelu(h) and gelu'(h) to the correctly rounded float64 values -- within one bf16 ulp wherever the
+    result is not deep in the negative tail (there: to 2e-7 |h| absolute, the A-S 7.1.26 erf's own error), and exactly h / 1 / -0 / 0 where
+    the function has saturated.  (reference: wavjepa/types/wavjepa_configs.py:37 activation = nn.GELU())"""
+    bits = torch.arange(65536, dtype=torch.int32)
+    vals = (bits << 16).view(torch.float32)
+    ok = torch.isfinite(vals) & (vals.abs() >= 2.0 ** -126)                   # normal, finite inputs (denormals are flushed on the way)
+    N, M, K = 65536, 256, 128
+    bias = torch.where(ok, vals, torch.zeros_like(vals)).to(dev())
+    A = torch.zeros(M, K, dtype=torch.bfloat16, device=dev())
+    W = rnd(N, K, scale=0.05, dtype=torch.bfloat16, seed=70)
+    gp = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    gl = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    prev = ops.gemm_set_variant(variant)
+    try:
+        ops.gemm(A, W, gp, C2=gl, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BIAS_GELU2, bias=bias)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_set_variant(prev)
+    assert torch.equal(gl[0].view(torch.int16), gl[M - 1].view(torch.int16)) and torch.equal(gp[0].view(torch.int16), gp[137].view(torch.int16))
+    h = vals.double()
+    cdf = 0.5 * torch.erfc(-h / math.sqrt(2.0))
+    pdf = torch.exp(-0.5 * h * h) / math.sqrt(2.0 * math.pi)
+    want = {"gelu": h * cdf, "gelu'": cdf + h * pdf}
+    got = {"gelu": gl[0].cpu(), "gelu'": gp[0].cpu()}
+
+    def ordinal(t):                                                           # bf16 bits -> integers ordered like the values
+        b = t.view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(b >= 0x8000, 0x8000 - b, b)
+
+    for name in want:
+        w = want[name].float().to(torch.bfloat16)
+        ulp = (ordinal(got[name]) - ordinal(w)).abs()
+        near = (got[name].double() - want[name]).abs() <= 2e-7 * h.abs().clamp(min=1.0)
+        bad = ok & (ulp > 1) & ~near
+        assert not bool(bad.any()), (name, variant, vals[bad][:8].tolist(), got[name][bad][:8].tolist(), w[bad][:8].tolist())
+        frac = float(((ulp > 0) & ok).float().sum() / ok.float().sum())
+        assert frac < 0.02, (name, variant, frac)                               # exactly rounded on > 98 % of the inputs
+        print(name, "variant", variant, "inputs off by one ulp or in the tail:", int(((ulp > 0) & ok).sum()), "of", int(ok.sum()))
+    big = ok & (vals >= 8.0)
+    assert torch.equal(got["gelu"][big].view(torch.int16), vals[big].to(torch.bfloat16).view(torch.int16))      # gelu(h) = h
+    assert bool((got["gelu'"][big].float() == 1.0).all())
