@@ -1065,3 +1065,30 @@ def test_gelu_epilogue_on_every_bf16_input(ops, variant):
     big = ok & (vals >= 8.0)
     assert torch.equal(got["gelu"][big].view(torch.int16), vals[big].to(torch.bfloat16).view(torch.int16))      # gelu(h) = h
     assert bool((got["gelu'"][big].float() == 1.0).all())
+
+
+def test_gelu_backward_kernel_on_every_bf16_input(ops):
+    """The conv stack's GELU backward (dpre = dpost * gelu'(pre), pre a bf16 tensor) on all 65 536 bf16 values of `pre` with dpost = 1 and
+    dpost = -0.75: within one bf16 ulp of the correctly rounded float64 product (or inside the erf approximation's 2e-7 |h| in the tail)."""
+    bits = torch.arange(65536, dtype=torch.int32)
+    vals = (bits << 16).view(torch.float32)
+    ok = torch.isfinite(vals) & (vals.abs() >= 2.0 ** -126)
+    pre = torch.where(ok, vals, torch.zeros_like(vals)).to(torch.bfloat16).to(dev())
+    h = vals.double()
+    gp = 0.5 * torch.erfc(-h / math.sqrt(2.0)) + h * torch.exp(-0.5 * h * h) / math.sqrt(2.0 * math.pi)
+
+    def ordinal(t):
+        b = t.view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(b >= 0x8000, 0x8000 - b, b)
+
+    for scale in (1.0, -0.75):
+        dpost = torch.full((65536,), scale, dtype=torch.bfloat16, device=dev())
+        out = torch.full((65536,), float("nan"), dtype=torch.bfloat16, device=dev())
+        ops.gelu_bwd_bf16(dpost, pre, out, 65536)
+        want = gp * scale
+        got = out.cpu()
+        ulp = (ordinal(got) - ordinal(want.float().to(torch.bfloat16))).abs()
+        near = (got.double() - want).abs() <= 2e-7 * h.abs().clamp(min=1.0)
+        bad = ok & (ulp > 1) & ~near
+        assert not bool(bad.any()), (scale, vals[bad][:8].tolist(), got[bad][:8].tolist(), want[bad][:8].tolist())
+        assert float(((ulp > 0) & ok).float().sum() / ok.float().sum()) < 0.02
