@@ -291,6 +291,13 @@ def main():
     ap.add_argument("--dense-steps", type=int, default=5, help="extra timed steps with the dense (non-ragged) shapes; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--seed", type=int, default=None,
+                    help="pin the masks (the maskers draw from OS entropy, as upstream) and the crop starts / shuffles: two runs with the same "
+                         "seed see the same batches (A/B comparisons of a loss; the default run stays unpinned)")
+    ap.add_argument("--emulate-allreduce", action="store_true",
+                    help="one GPU: at every gradient-bucket hook a copy kernel confined to the CUs a data-parallel run leaves free moves 2 x the "
+                         "bucket's bytes on a communication stream (the HBM + CU footprint of reduce-scatter + all-gather); an EMULATION, "
+                         "reported as `allreduce_emulated`, never part of a scaling record")
     args = ap.parse_args()
 
     from wavjepa_amd.data import SyntheticAudioSource
@@ -328,11 +335,35 @@ def main():
                                     target_length=10, ratio_cutoff=0.1, channel_based_masking=nat, channel_major=nat)   # configs/masker/AudioSet.yaml
     src_kw = dict(batch_size=args.clips_per_gpu // S, samples_per_audio=S, n_tokens=model.total_patches, seed=42 + rank, n_mask_sets=64,
                   device=device)                                                      # masks pre-generated for 64 steps and cycled
-    if nat:
-        from wavjepa_amd.data import NatSceneSource
-        source = NatSceneSource(masker, **src_kw)          # scene generation runs inside the timed step (next_batch)
-    else:
-        source = SyntheticAudioSource(masker, **src_kw)
+    import contextlib
+    import numpy as np
+
+    @contextlib.contextmanager
+    def pinned_masks(seed):
+        """Inside: the k-th np.random.default_rng() call of the maskers returns default_rng(seed + k) (--seed)."""
+        if seed is None:
+            yield
+            return
+        orig, k = np.random.default_rng, [0]
+
+        def pinned(_seed=None):
+            k[0] += 1
+            return orig(seed + 1000 * rank + k[0])
+        np.random.default_rng = pinned
+        try:
+            yield
+        finally:
+            np.random.default_rng = orig
+
+    with pinned_masks(args.seed):
+        if nat:
+            from wavjepa_amd.data import NatSceneSource
+            source = NatSceneSource(masker, **src_kw)          # scene generation runs inside the timed step (next_batch)
+        else:
+            source = SyntheticAudioSource(masker, **src_kw)
+    if args.seed is not None:            # crop starts (device generator) and the crop shuffle (CPU generator) of on_after_batch_transfer
+        torch.manual_seed(args.seed + rank)
+        torch.cuda.manual_seed(args.seed + rank)
     runner = StepRunner(model, gradient_clip_val=5.0)
     # Data-parallel runs leave CUs to RCCL: a persistent GEMM workgroup owns its CU's whole register file and 150 KB of its LDS, so a
     # channel kernel of the gradient all-reduce can only start on a CU the persistent kernel does not occupy.  28 of 32 workgroups per

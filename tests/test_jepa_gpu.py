@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from tests import launch
+from tests import parity_yardstick as Y
 import synth
 from oracle import jepa_oracle as J
 
@@ -94,6 +95,11 @@ def oracle_kw(cfg):
     return dict(spec=cfg["conv_spec"], enc_heads=cfg["h_enc"], dec_heads=cfg["h_dec"], top_k=cfg["top_k"])
 
 
+def channel_group_of(name):
+    """group_of, with every channel's conv stack of a ConvChannelFeatureExtractor as its own group"""
+    return ".".join(name.split(".")[:3]) if name.startswith("extract_audio.cnns") else group_of(name)
+
+
 def group_of(name):
     for g in ("extract_audio", "feature_norms", "post_extraction_mapper", "encoder_to_decoder_mapper",
               "decoder_to_encoder_mapper", "encoder", "decoder", "mask_token"):
@@ -154,32 +160,35 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     # bf16 flow is.  Two INDEPENDENT bf16 pipelines then sit up to sqrt(2) x that distance apart (measured at 64 clips: 0.86 % between
     # them with both 0.61-0.63 % from fp32; at 2 clips the rounding errors happen to correlate and 0.66 % is seen), which is what the
     # fixed bounds of ACT_TOL (1.25 x the 2-clip distances) cannot express for a large batch.
-    to32 = {k: (rel(out[k].float(), ref32[k].float()), rel(ref[k].float(), ref32[k].float())) for k in ("local_features", "targets")}
+    to32 = {k: (rel(out[k].float(), ref32[k].float()), rel(ref[k].float(), ref32[k].float()))
+            for k in ("local_features", "targets", "contextual_features")}
+    to32["preds"] = (rel(out["preds"][seen].float(), ref32["preds"][seen].float()), rel(ref["preds"][seen].float(), ref32["preds"][seen].float()))
     print(cfg_name, "distance from the fp32 oracle (HIP, oracle-bf16):", to32)
     for k, (d_hip, d_orc) in to32.items():
-        assert d_hip < 1.1 * d_orc + 2e-4, (k, d_hip, d_orc)
-    for k, bound in ACT_TOL[cfg_name].items():
-        if n >= 16 and k in to32:
-            bound = max(bound, 1.5 * to32[k][1])
-        elif n >= 16 and k == "contextual_features":
-            bound = max(bound, 1.5 * to32["targets"][1])
-        assert report[k] < bound, (k, report[k], bound)
+        # the yardstick form (tests/parity_yardstick.py), at every batch size: as close to fp32 as the oracle's bf16 flow on this draw,
+        # and within the distance of two independent bf16 pipelines from that flow
+        assert d_hip < Y.ACT_FACTOR * d_orc + Y.ACT_EPS, (k, d_hip, d_orc)
+        assert report[k] < Y.PAIR_FACTOR * d_orc + Y.ACT_EPS, (k, report[k], d_orc)
+    if n < 16:
+        # small batches also keep the fixed regression bounds anchored on the stock-autocast distances
+        for k, bound in ACT_TOL[cfg_name].items():
+            assert report[k] < bound, (k, report[k], bound)
     assert abs(lo - lr_) < 1e-3 * abs(lr_), (lo, lr_)          # north-star: loss within 1e-3 rel of the bf16 reference flow
     assert abs(lo - l32) < 2e-2 * abs(l32)
     # backward
     out["loss"].backward()
     ref["loss"].backward()
-    got = dict(m.named_parameters())
-    num, den = {}, {}
-    for k in names:
-        g = group_of(k)
-        a, b = got[k].grad.double(), P[k].grad.double()
-        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
-        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
-    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    gbf = {k: P[k].grad for k in names}
+    errs = Y.group_errors(got, gbf, names, group_of)
     print(cfg_name, "grad rel errors per group:", errs)
     for g, e in errs.items():
         assert e < GRAD_TOL[cfg_name], (g, e)
+    # gradient yardstick: per group, HIP is as close to the oracle's fp32 gradient as the oracle's own bf16 flow is on this draw
+    _, g32 = Y.oracle_fp32_grads(J, P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), names, **oracle_kw(cfg))
+    table = Y.grad_yardstick(got, gbf, g32, names, group_of)
+    print(cfg_name, "grad yardstick (d_hip, d_orc, pair, ratio):", {g: tuple(round(v, 5) for v in r.values()) for g, r in table.items()})
+    Y.assert_grad_yardstick(table)
 
 
 def test_batch_size_changes_between_steps(golden_dir):
@@ -475,7 +484,7 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank():
 
 def test_bench_one_rank_gradient_buckets_through_the_librarys_rccl_binding():
     """WJ_RCCL_DIRECT=1: the buckets leave through wj_rccl_bucket_allreduce_{launch,wait} (own communicator, own stream) instead
-    of torch.distributed.  One rank: the average is the identity, so the run must land near the default transport's loss."""
+    of torch.distributed.  One rank: the average is the identity, so the run must land on the default transport's loss (same seed)."""
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -483,16 +492,19 @@ def test_bench_one_rank_gradient_buckets_through_the_librarys_rccl_binding():
     for direct in ("0", "1"):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", str(launch.free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-               "--clips-per-gpu", "16", "--dense-steps", "0", "--no-cpu-baseline", "--no-profile"]
+               "--clips-per-gpu", "16", "--dense-steps", "0", "--no-cpu-baseline", "--no-profile", "--seed", "4242"]
         rc, out, err = launch.run(cmd, cwd=root, env=dict(os.environ, WJ_RCCL_DIRECT=direct), timeout=300)
         assert rc == 0, err[-4000:]
         lines[direct] = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     a, b = lines["0"], lines["1"]
     assert b["replicas_equal"] is True and b["config"]["gradient_transport"] == "wj_rccl_bucket_allreduce" and a["config"]["gradient_transport"] == "torch.distributed"
     assert b["allreduce"] is not None and b["allreduce"]["buckets"] >= 2 and b["allreduce"]["exposed_ms"] >= 0
-    # the two processes draw their own masks and crops (OS entropy, as the reference's masker does): at 16 clips the loss of a step moves
-    # by ~0.3 % from draw to draw; a transport that lost or doubled a bucket would leave NaN / a diverging loss behind three AdamW steps
-    assert abs(a["final_loss"] - b["final_loss"]) < 2e-2 * abs(a["final_loss"]), (a["final_loss"], b["final_loss"])
+    # both processes see the same masks, crops and shuffles (--seed): the two transports must land on the same loss up to the fp32-atomic
+    # noise of the weight gradients (a bucket that was lost, reduced twice or read before its launch moves the loss of the next step).
+    # What this does NOT show: ncclAvg over more than one rank and the comm-stream ordering under a real collective -- a world of one
+    # is the identity; that stays unverified until a multi-GPU node runs it.
+    assert abs(a["final_loss"] - b["final_loss"]) < 2e-4 * abs(a["final_loss"]), (a["final_loss"], b["final_loss"])
+    assert a["param_checksum"][1] == pytest.approx(b["param_checksum"][1], rel=1e-6)
 
 
 def test_bench_two_ranks_share_the_gpu_over_gloo():
@@ -534,7 +546,7 @@ def test_forward_backward_parity_channel_extractor(stacks, ragged):
     m, P = build(SMALL, seconds=1.0, tokens=198, in_channels=2, channel_stacks=stacks)
     assert m.total_patches == 198 and m.extract_audio.frames_per_channel(16000) == 99
     m._ensure_engine().ragged = ragged
-    with PinnedRng(4100):
+    with PinnedRng(4100):                # reproducibility only: the bounds below are yardstick bounds, valid on any draw
         ctx, tgt, vis = TimeInverseBlockMasker(4, 0.65, 10, 0.25, 10, 0.1, channel_based_masking=True, channel_major=True)(
             batch_size=3, n_times=198, in_channels=2)
     assert ctx.shape == (3, 198) and torch.equal(ctx[:, :99], ctx[:, 99:])
@@ -551,19 +563,22 @@ def test_forward_backward_parity_channel_extractor(stacks, ragged):
     assert rel(out["targets"].float(), ref["targets"].float()) < 1e-2
     out["loss"].backward()
     ref["loss"].backward()
-    got = dict(m.named_parameters())
-    num, den = {}, {}
-    for k in names:
-        g = ".".join(k.split(".")[:3]) if k.startswith("extract_audio.cnns") else group_of(k)     # each stack on its own
-        a, b = got[k].grad.double(), P[k].grad.double()
-        num[g] = num.get(g, 0.0) + float((a - b).pow(2).sum())
-        den[g] = den.get(g, 0.0) + float(b.pow(2).sum())
-    errs = {g: (num[g] / max(den[g], 1e-300)) ** 0.5 for g in num}
-    print(stacks, "ragged" if ragged else "dense", "loss", lo, lr_, "grad rel errors per group:", errs)
-    assert sum(1 for g in errs if g.startswith("extract_audio.cnns")) == (2 if stacks == "own" else 1)
-    for g, e in errs.items():
-        # a per-channel conv stack sees half of the tokens of a clip: its gradient is the noisiest group (measured 0.9-1.6 %)
-        assert e < (2.5e-2 if g.startswith("extract_audio.cnns") else GRAD_TOL["small"]), (g, e)
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    gbf = {k: P[k].grad for k in names}
+    _, g32 = Y.oracle_fp32_grads(J, P, audio, ctx.to(dev()), tgt.to(dev()), vis.to(dev()), names, **oracle_kw(SMALL))
+    table = Y.grad_yardstick(got, gbf, g32, names, channel_group_of)          # each stack on its own
+    print(stacks, "ragged" if ragged else "dense", "loss", lo, lr_, "grad yardstick (d_hip, d_orc, pair, ratio):",
+          {g: tuple(round(v, 5) for v in r.values()) for g, r in table.items()})
+    assert sum(1 for g in table if g.startswith("extract_audio.cnns")) == (2 if stacks == "own" else 1)
+    # A per-channel conv stack sees half of the tokens of a clip and is the noisiest group: its distance from the oracle's bf16 flow
+    # moves between 0.9 % and 2.5 % with the mask draw (the round-4 fixed bound of 2.5e-2 failed on some draws).  That is the
+    # oracle's OWN bf16 distance from fp32 on those draws -- profiles/r05_grad_yardstick.txt, 2 x 16 unpinned draws: oracle-bf16 vs
+    # fp32 1.03-2.23 %, HIP vs fp32 0.82-2.10 % -- so the bound is stated against it (factor 1.5 for these groups: per draw the two
+    # are independent realisations of the same noise, ratio 0.79-1.36; 1.25 for every other group).
+    Y.assert_grad_yardstick(table)
+    for g, r in table.items():
+        if not g.startswith("extract_audio.cnns"):
+            assert r["pair"] < GRAD_TOL["small"], (g, r)
     # the stand-alone extractor forward gives the same tokens as the oracle's front-end
     tok = m.extract_audio(audio)
     want = J.conv_frontend({k: v.detach() for k, v in P.items()}, audio, SMALL_SPEC, "bf16")

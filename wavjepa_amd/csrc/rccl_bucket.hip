@@ -5,11 +5,24 @@
 // library directly for a host that has no torch.distributed: one communicator per process (= per GPU), in-place average (or sum) of a
 // contiguous fp32 bucket on the stream the caller names, and a stream-level wait.  RCCL is resolved at run time (dlopen: the copy the
 // process already holds -- PyTorch-ROCm ships one -- or the system one), so the library loads, and everything else works, on hosts
-// without it.  Host code only: no kernels in this file.
+// without it; the RCCL header is optional at build time too (declarations below).  Host code only: no kernels in this file.
+// Verification status: exercised on the GPU with a world of ONE rank only (ncclAvg is then the identity); no multi-GPU node has run
+// it, so the multi-rank average and the comm-stream ordering are unverified on hardware.
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// Build host without the RCCL development headers: the few declarations the binding needs, as RCCL's public header states them
+// (nccl.h ABI: a 128-byte unique id, an opaque communicator, result 0 = success, ncclFloat32 = 7, ncclSum = 0, ncclAvg = 4).  The
+// library is still resolved at run time; without it the entries answer WJ_ERR_UNSUPPORTED.
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclAvg = 4 } ncclRedOp_t;
+#endif
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
 

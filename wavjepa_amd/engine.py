@@ -408,7 +408,7 @@ class JepaEngine:
                         setattr(w, k + "T", self.p16t.data_ptr() + 2 * f.by_name[getattr(w, k + "_name")].offset)
             else:
                 self.wt_dgrad = False          # a width that is not a multiple of 64: keep the col-form dgrads
-        self._wt_fresh = False
+        self._wt_fresh = None                  # the `_wt_need` the shadows were last refreshed for (None: stale)
         self._wt_live = {}
 
     @staticmethod
@@ -481,7 +481,7 @@ class JepaEngine:
             f.bf16_fresh = True
         if self.fp8:
             self._fp8_weights()
-        self._wt_fresh = False                      # the shadows follow p16; refreshed by the first backward that needs them
+        self._wt_fresh = None                       # the shadows follow p16; refreshed by the first backward that needs them
         self._conv_w_fresh = False                  # GEMM layouts of conv layers 1..: rebuilt by the front-end, behind its conv0 launches
 
     def _conv_weight_layouts(self) -> None:
@@ -744,9 +744,11 @@ class JepaEngine:
         """bf16 W^T shadows from the current bf16 weights: one batched transpose of the weights this step's dgrads read in row form
         (`_wt_need`: with the AudioSet masker at 256 clips all four of every predictor layer and linear2 of every student layer,
         99 of the 213 MB of transformer weights); once per prepared set of weights."""
-        if not self.wt_dgrad or self._wt_fresh:
-            return
         need = self._wt_need
+        # fresh only for the set of weights it was refreshed for: a second grad-enabled forward on the same prepared weights with other
+        # row counts (direct engine use, gradient accumulation) needs other shadows, which would still hold zeros / older weights
+        if not self.wt_dgrad or self._wt_fresh == need:
+            return
         if need not in self._wt_tables:
             f, rows, tiles = self.flat, [], 0
             for layers, keys in ((self.enc_layers, need[0]), (self.dec_layers, need[1])):
@@ -760,7 +762,7 @@ class JepaEngine:
         table, n_mats, n_tiles = self._wt_tables[need]
         if n_mats:
             ops.transpose_bf16(self.flat.p16, self.p16t, table, n_mats, n_tiles)
-        self._wt_fresh = True
+        self._wt_fresh = need
 
     def _dgrad(self, dY, w: _Layer, key: str, out, *, M: int, N: int, K: int, **kw) -> None:
         """out[M, N] = dY[M, K] . W   (W = the layer's `key` weight, stored [K][N] as nn.Linear keeps it): against the W^T shadow as a
@@ -1076,8 +1078,10 @@ class JepaEngine:
         section_final = ready
 
         def ready(tag):                  # a section is final only once the pending parameter-gradient folds have been queued
-            self._flush_folds()
+            if on_grads_ready is not None:       # (no consumer of sections: the folds go out in full groups and at the end)
+                self._flush_folds()
             section_final(tag)
+        self._folds = []                 # entries an exception in an earlier backward may have left behind must not be folded into this one
         c, f, plan = self.cfg, self.flat, self.plan
         N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, self.G, self.C
         De, Dd = c.d_enc, c.d_dec
