@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 13
+#define WJ_ABI_VERSION 14
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -66,6 +66,11 @@ typedef struct {
     int32_t split_k;
     int32_t seg_rows, seg_valid;
     float alpha;
+    void* workspace;         /* optional scratch, wj_workspace_bytes("wj_gemm_bf16", args) bytes, ZERO-FILLED ONCE by the caller and then */
+    int64_t workspace_bytes; /* left to the library (one per stream that launches GEMMs concurrently).  With it, row-form WJ_EPI_BF16
+                                problems of 33-128 output tiles and K >= 1536 (the ragged student's N = 768 linears and dgrads: 117 tiles
+                                for 256 CUs) run as K-split PAIRS: two workgroups per tile, half of K each, fp32 partial sums exchanged
+                                through the scratch (csrc/gemm.hip).  NULL / too small: one workgroup per tile, as before. */
 } wj_gemm_args;
 int wj_gemm_bf16(const wj_gemm_args*, void* stream);
 /* ------------------------------------------------------------------------------------------------------------

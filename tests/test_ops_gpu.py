@@ -143,6 +143,63 @@ def test_gemm_persistent_schedule(ops, M, N, K, epi):
             assert relerr(C4.float(), hb * valid) < 4e-3 and relerr(C24.float(), g * valid) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(9945, 768, 3072),       # the ragged student's linear2 / linear1-dgrad: 117 tiles -> 234 workgroups
+                                   (9945, 768, 2304),       # in_proj dgrad (18 K tiles per half)
+                                   (8500, 1024, 1536),      # 34 x 4 = 136 tiles: too many for one round -> stays unsplit (same bits)
+                                   (2200, 1024, 1536),      # 36 tiles, M edge inside the last panel
+                                   (16384, 512, 1536)])     # 128 tiles: the largest split problem (every XCD: 16 + 16 workgroups)
+def test_gemm_k_split_pairs(ops, M, N, K):
+    """K-split pairs of the eight-phase schedule (wj_gemm_args.workspace): two workgroups per output tile, half of K each, fp32 partial
+    sums exchanged through the scratch.  Through the C ABI on NaN-filled outputs: against the fp32 reference at bf16 resolution; against
+    the unsplit launch only last-place differences (fp32 sums of two halves instead of one chain); five launches bit-identical (a flag
+    left set, a partial read before it was posted or a tile half nobody finished would show); the scratch's flags are back at zero."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=21)
+    W = rnd(N, K, scale=0.05, dtype=torch.bfloat16, seed=22)
+    bias = rnd(N, seed=23)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+    need = ops.workspace_bytes("wj_gemm_bf16", M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BF16)
+    tiles = -(-M // 256) * (N // 256)
+    assert (need > 0) == (32 < tiles <= 128)
+    ws = torch.zeros(max(need, 256), dtype=torch.uint8, device=dev())
+
+    def run(workspace):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        ops.gemm(A, W, C, workspace=workspace, **kw)
+        torch.cuda.synchronize()
+        return C
+
+    C0 = run(None)
+    C1 = run(ws)
+    assert not bool(torch.isnan(C1.float()).any())
+    for _ in range(4):
+        assert torch.equal(run(ws).view(torch.int16), C1.view(torch.int16))
+    assert int(ws[:tiles * 8].view(torch.int32).abs().sum()) == 0          # every flag consumed
+    h = A.float() @ W.float().t() + bias
+    assert relerr(C1.float(), h) < 4e-3
+    d = (C0.float() - C1.float()).abs()
+    if need == 0:
+        assert torch.equal(C0.view(torch.int16), C1.view(torch.int16))
+    else:
+        assert float((d > 0).float().mean()) < 2e-2
+        assert bool((d <= 2.0 ** -6 * torch.maximum(C0.float().abs(), C1.float().abs()) + 4e-3).all())
+    if need:
+        # a second product through the same scratch, alternating with the first: a partial sum read from a stale cache line (the
+        # partner's workgroup runs on another CU, usually another XCD = another L2) would carry the OTHER product's values
+        A2 = rnd(M, K, dtype=torch.bfloat16, seed=24)
+        h2 = A2.float() @ W.float().t() + bias
+        C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        for it in range(6):
+            ops.gemm(A2, W, C2, workspace=ws, **kw)
+            ops.gemm(A, W, C0, workspace=ws, **kw)           # back to back, no host synchronisation in between
+        torch.cuda.synchronize()
+        assert relerr(C2.float(), h2) < 4e-3 and torch.equal(C0.view(torch.int16), C1.view(torch.int16))
+        C0 = run(None)
+    # a scratch that is too small is ignored (one workgroup per tile), not overrun
+    if need:
+        small = torch.zeros(need // 2, dtype=torch.uint8, device=dev())
+        assert torch.equal(run(small).view(torch.int16), C0.view(torch.int16)) and int(small.view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,N,K,cus", [(33100, 384, 384, 32),      # a full + a half-width item per 256-row panel, shifted M edge
                                         (33100, 640, 256, 32),      # two full tiles + a half-width item
                                         (40000, 384, 1152, 28),     # fewer resident workgroups per XCD (the data-parallel default)
@@ -267,7 +324,11 @@ def test_gemm_wgrad_layout(ops, Mtok, Nout, Kin, split):
 @pytest.mark.parametrize("dims,K", [([(384, 128), (128, 128), (512, 128), (128, 512)], 1000), ([(192, 64), (64, 64), (256, 64), (64, 256)] * 2, 777),
                                     ([(2304, 768), (768, 768)], 2500),
                                     # a predictor layer (every shape has a 384: half-full row tiles of the 256 x 128 schedule) and a 72-row tail
-                                    ([(1152, 384), (384, 384), (1536, 384), (384, 1536), (328, 256)], 9000)])
+                                    ([(1152, 384), (384, 384), (1536, 384), (384, 1536), (328, 256)], 9000),
+                                    # exactly a predictor layer: every problem a multiple of 384 x 128 -> the 384 x 128 tile (36 full tiles,
+                                    # split-K 7; K with a tail that is not a multiple of the 32-deep K tile), and two layers' worth in one group
+                                    ([(1152, 384), (384, 384), (1536, 384), (384, 1536)], 21001),
+                                    ([(1152, 384), (384, 384), (1536, 384), (384, 1536)] * 2, 5000)])
 def test_wgrad_grouped(ops, dims, K):
     """Several dW = dY^T X problems in one launch (one split-K factor for the group) == the individual fp32 products, accumulated
     on top of what the gradient buffers already hold."""

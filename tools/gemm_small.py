@@ -20,7 +20,12 @@ for (m, N, K) in SHAPES:
     W = (torch.randn(N, K, device=dev) * 0.05).to(bf)        # row form [N][K]
     Wt = W.t().contiguous()                                  # col form [K][N]: the nn.Linear weight of the dgrad
     C = torch.empty(m, N, device=dev, dtype=bf)
+    need = ops.workspace_bytes("wj_gemm_bf16", M=m, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BF16)
+    os.environ.setdefault("WJ_PAIR_MIN_K", "256")           # (read once by the library: set before the first launch to try short K too)
+    ws = torch.zeros(max(need, 256), dtype=torch.uint8, device=dev)
     cases = [("row v0", 0, False), ("row v2", 2, False), ("row v3", 3, False), ("row v4", 4, False), ("col v0", 0, True)]
+    if need:
+        cases.append(("row v3 pair", 3, False))
     ts = {(c[0], mode): [] for c in cases for mode in ("warm", "cold")}
     for r in range(14):
         for mode in ("warm", "cold"):
@@ -33,7 +38,7 @@ for (m, N, K) in SHAPES:
                 if col:
                     ops.gemm(A, Wt, C, M=m, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1)
                 else:
-                    ops.gemm(A, W, C, M=m, N=N, K=K, lda=K, ldb=K, ldc=N)
+                    ops.gemm(A, W, C, M=m, N=N, K=K, lda=K, ldb=K, ldc=N, workspace=ws if name.endswith("pair") else None)
                 e1.record()
                 torch.cuda.synchronize()
                 if r > 1:

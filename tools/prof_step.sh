@@ -3,7 +3,7 @@
 # For every configuration: the serial kernel-time sum of the training step (the round-4 accept criterion: bench.py with
 # WJ_SIDE_STREAM=0 under rocprofv3 --kernel-trace --stats), then the single-stream and the two-stream step times of the same build.
 # Configurations of ONE call run on ONE box back to back: compare only those (boxes differ by ~4 % in sustained clock).
-# Outputs under gpurun_out/r4/<tag>/: run_kernel_stats.csv, serial_sum.txt, step_1s.json, step_2s.json
+# Outputs under gpurun_out/${WJ_ROUND:-r5}/<tag>/: run_kernel_stats.csv, serial_sum.txt, step_1s.json, step_2s.json
 set -u
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
@@ -14,7 +14,7 @@ for cfg in "$@"; do
   tag=${cfg%%:*}
   envs=""
   [ "$cfg" != "$tag" ] && envs=${cfg#*:}
-  out=$root/gpurun_out/r4/$tag
+  out=$root/gpurun_out/${WJ_ROUND:-r5}/$tag
   mkdir -p "$out"
   (
     IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS

@@ -35,17 +35,20 @@
 namespace {
 
 constexpr int BM = 256, BK = 32, NT = 512;
+constexpr long PAIR_TILE_BYTES = 2L * 4 * 32 * 64 * 16;   // K-split pairs: scratch per output tile (two roles x four waves' accumulators)
 
-template <int BN> struct Cfg {
-    static constexpr int STAGES = BN == 256 ? 4 : 3;
-    static constexpr int A_BYTES = BM * BK * 2;                        // 16384
+// BMT: tile rows.  256 everywhere except the 384 x 128 tile of the predictor's grouped weight gradients (every dimension of those
+// products is a multiple of 384: with 256-row tiles 14 % of their MFMA work fell on rows past the edge).
+template <int BN, int BMT = 256> struct Cfg {
+    static constexpr int STAGES = (BN == 256 || BMT == 384) ? 4 : 3;
+    static constexpr int A_BYTES = BMT * BK * 2;                       // 16384 (24576 for 384 rows)
     static constexpr int B_BYTES = BN * BK * 2;                        // 16384 / 8192
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;              // 32768 / 24576
     static constexpr int RING_BYTES = STAGES * STAGE_BYTES;            // 131072 / 73728
     static constexpr int LOADS_PER_TILE = STAGE_BYTES / 1024 / 8;      // LDS-DMA instructions per wave per K tile: 4 / 3
     static constexpr int WAVES_N = BN / 64;                            // 4 / 2
     static constexpr int WAVES_M = 8 / WAVES_N;                        // 2 / 4
-    static constexpr int MI = BM / WAVES_M / 16;                       // m-fragments per wave: 8 / 4
+    static constexpr int MI = BMT / WAVES_M / 16;                      // m-fragments per wave: 8 / 4 (6 for 384 x 128)
     static constexpr int CP_BF16 = BN * 2 + 16;                        // C staging pitch, bf16
     static constexpr int CP_F32 = BN * 4 + 16;                         // fp32
     // C staging: rows per chunk.  The 256-wide tile asks for 132 KiB of LDS (still one workgroup per CU) so that a bf16 tile is
@@ -105,11 +108,11 @@ __device__ __forceinline__ void stage_tile(char* lds_tile, const bf16_t* __restr
         } else {
             // [32 k][ROWS] image: LDS position (k row, chunk p) holds source chunk p ^ (f(k) << 1),
             // f(k) = (k & 3) | ((k >> 3) & 1) << 2  -> the 8 k-rows one transposed read touches hit 8 distinct 32-B columns
-            constexpr int CPR = ROWS / 8;   // 16-B chunks per k row
-            constexpr int RPI = 64 / CPR;   // k rows per wave-instruction
-            const int krow = j * RPI + lane / CPR;
+            constexpr int CPR = ROWS / 8;   // 16-B chunks per k row (16 / 32 / 48: the image is chunk-linear, a wave-instruction = 64 chunks)
+            const int q = j * 64 + lane;
+            const int krow = q / CPR;
             const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
-            const int c = (lane % CPR) ^ (f << 1);
+            const int c = (q % CPR) ^ (f << 1);        // the XOR stays inside a group of 16 chunks
             const int k = k0 + krow;
             const int row = r0 + c * 8;
             src = sel_ptr(k < kend && row < R, base + (long)k * ld + row, zero);
@@ -141,10 +144,11 @@ struct TilePtrs {
                 p[u] = reinterpret_cast<const char*>(base + (long)grow * ld + kbeg + c * 8);
                 step[u] = BK * 2;
             } else {
-                constexpr int CPR = ROWS / 8, RPI = 64 / CPR;
-                const int krow = j * RPI + lane / CPR;
+                constexpr int CPR = ROWS / 8;
+                const int q = j * 64 + lane;
+                const int krow = q / CPR;
                 const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
-                const int c = (lane % CPR) ^ (f << 1);
+                const int c = (q % CPR) ^ (f << 1);
                 const int row = r0 + c * 8;
                 const bool ok = row < R;
                 p[u] = reinterpret_cast<const char*>(sel_ptr(ok, base + (long)(kbeg + krow) * ld + row, zero));
@@ -202,6 +206,38 @@ __device__ __forceinline__ void load_frags4(bf16x8* f, const char* tile, int rba
     }
 }
 
+// two fragments (tile rows rbase0 + 16x + i, x < 2): the tail of a wave's six m-fragments in the 384-row tile
+template <bool TRANS, int ROWS>
+__device__ __forceinline__ void load_frags2(bf16x8* f, const char* tile, int rbase0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if constexpr (!TRANS) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int row = rbase0 + x * 16 + i;
+            f[x] = *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((g ^ row_swz(row)) << 4));
+        }
+    } else {
+        const int q = i >> 2, p = i & 3;
+        const int k = 8 * g + q;
+        const int fx = (q | ((g & 1) << 2)) << 5;
+        const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)tile + k * (ROWS * 2);
+        const unsigned a0 = base + ((((rbase0 + 0) + 4 * p) << 1) ^ fx);
+        const unsigned a1 = base + ((((rbase0 + 16) + 4 * p) << 1) ^ fx);
+        bf16x4 l0, h0, l1, h1;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %4\n\t"
+            "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+            "ds_read_b64_tr_b16 %2, %5\n\t"
+            "ds_read_b64_tr_b16 %3, %5 offset:%6\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1)
+            : "v"(a0), "v"(a1), "n"(4 * ROWS * 2)
+            : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
 struct EpiArgs {
     void* C;
     void* C2;
@@ -218,6 +254,8 @@ struct EpiArgs {
     unsigned char* q_out;    // GELU epilogues, optional: gelu(h) also as MX fp8 (bytes [M][ldc]) + block scales [N / 128][ld_q] dwords
     uint32_t* q_scales;
     long ld_q;
+    float* pair_ws;          // K-split pairs (eight-phase schedule, pair_split below): [tiles][2 roles][4 waves][32 regs][64 lanes] float4
+    unsigned* pair_flags;    //   [tiles][2]: role r's half of the partial sums is posted (reset to 0 by the partner that consumed it)
 };
 
 template <int N>
@@ -620,12 +658,16 @@ __device__ __forceinline__ void eight_phase_loop_fp8(f32x4 (&acc)[8][4], char* s
 // the list is padded with >= 256 readable entries).
 // The body of one workgroup: `bid` of `nwg` workgroups of ONE problem (the plain kernel passes blockIdx / gridDim; the grouped
 // kernel below passes the workgroup's position inside its problem of the group).
-template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
+template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0, int BMT = 256>
 __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, long lda, long ldb, int M, int N,
-                                           int K, int tiles_n, int split_k, int k_per_split, const EpiArgs& e, int bid, int nwg) {
-    using C_ = Cfg<BN>;
+                                           int K, int tiles_n, int split_k, int k_per_split, const EpiArgs& e, int bid, int nwg,
+                                           bool remapped = false) {
+    // remapped: `bid` already is the logical (XCD-grouped) position inside the problem (grouped launches remap over the whole group)
+    using C_ = Cfg<BN, BMT>;
+    constexpr int BM = BMT;              // (shadows the file-level 256 inside this body)
+    static_assert(BMT == 256 || (BMT == 384 && BN == 128 && SCHED < 2 && GATHER == 0), "384-row tiles: 384 x 128, plain / ping-pong schedule");
     constexpr bool STAGGER = SCHED == 1;
-    static_assert(SCHED == 0 || BN == 256, "the ping-pong / eight-phase schedules are built for the 8-wave 256x256 tile");
+    static_assert(SCHED == 0 || BN == 256 || (SCHED == 1 && BMT == 384), "the ping-pong / eight-phase schedules are built for one 8-wave workgroup per CU");
     static_assert(GATHER == 0 || SCHED == 0, "gather forms use the plain schedule");
     static_assert(SCHED < 2 || (!AT && !BT), "eight-phase schedules: row-form operands");
     static_assert(SCHED != 3 || EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2, "MX fp8 loop: forward epilogues");
@@ -638,10 +680,31 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
     const int wm = wave / C_::WAVES_N, wn = wave % C_::WAVES_N;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
-    const int wg = xcd_remap(bid, nwg);
+    // K-split PAIRS (eight-phase schedule, SCHED 2, split_k == 2; launch_pair below): problems with 64-128 output tiles leave half of
+    // the 256 CUs idle (the ragged student: M ~ 10 k rows x N = 768 = 117 tiles).  Two workgroups share a tile, each multiplies half of
+    // K, then they exchange HALF of their fp32 partial sums through `pair_ws` -- role r keeps tile rows [128 r, 128 r + 128), i.e. its
+    // waves with wm == r, and posts the accumulators of its other four waves -- and each finishes its half of the tile.  The exchange
+    // is layout-free: a wave stores its accumulator registers as they are (register x lane, 16-byte coalesced) and the partner's wave
+    // with the same index reads them back into the same registers.
+    // Mapping: an XCD (bid % 8) owns a contiguous run of tiles; its workgroups j = bid / 8 are first the role-0 then the role-1
+    // workgroups of those tiles, so both halves of an A panel stay on one L2 and the tiles of a panel run side by side.  Posting never
+    // blocks and a pair's workgroups are `len` dispatch slots apart on one XCD: a workgroup that waits for its partner cannot starve it.
+    constexpr bool PAIR_OK = SCHED == 2 && EPI == WJ_EPI_BF16;
+    const bool pair = PAIR_OK && split_k == 2;
+    int wg = 0, role = 0;
+    if (pair) {
+        const int nt = tiles_n * ((M + BM - 1) / BM);      // tiles of the problem
+        const int x = bid & 7, j = bid >> 3, tq = nt >> 3, tr = nt & 7;
+        const int len = tq + (x < tr ? 1 : 0), start = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
+        if (j >= 2 * len) return;                 // grid padding
+        role = j >= len ? 1 : 0;
+        wg = role * nt + start + (role ? j - len : j);
+    } else {
+        wg = remapped ? bid : xcd_remap(bid, nwg);
+    }
     // split-K work order: K-slice major, tile minor -> the tiles that stream the same K-slice of A / B are neighbours on one
     // XCD and share it through L2 (tile-major order fetched ~3x the algorithmic bytes: profiles/r01_pmc_traffic.json)
-    const int ntiles = nwg / split_k;
+    const int ntiles = pair ? tiles_n * ((M + BM - 1) / BM) : nwg / split_k;
     const int ksl = wg / ntiles, tile = wg - ksl * ntiles;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -695,7 +758,69 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
     if constexpr (SCHED == 3) {
         eight_phase_loop_fp8(acc, smem, reinterpret_cast<const char*>(A), reinterpret_cast<const char*>(B), lda, ldb, m0, n0, M, N, K, e, wave, lane);
     } else if constexpr (SCHED == 2) {
-        eight_phase_loop(acc, smem, A, B, lda, ldb, m0, n0, M, N, K, wave, lane);
+        eight_phase_loop(acc, smem, A + kbeg, B + kbeg, lda, ldb, m0, n0, M, N, kend - kbeg, wave, lane);
+        if constexpr (PAIR_OK) {
+            if (pair) {
+                // post the accumulators of the waves whose rows the partner finishes, take the partner's for the rows kept here.
+                // Coherence between the two workgroups (different CUs, possibly different XCDs = different L2s) is carried by the
+                // ACCESSES, not by fences: agent-scope (sc1) stores write through the L2, agent-scope loads do not hit stale lines.
+                // (Release / acquire fences -- buffer_wbl2 / buffer_inv of the whole L2 from 234 workgroups -- cost ~90 us per launch.)
+                char* ws = reinterpret_cast<char*>(e.pair_ws) + (size_t)tile * PAIR_TILE_BYTES;
+                unsigned* flags = e.pair_flags + tile * 2;
+                const long slot = ((long)((wave & 3) * 32) * 64 + lane) * 16;
+                if (wm != role) {
+                    char* dst = ws + (size_t)role * (PAIR_TILE_BYTES / 2) + slot;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (a * 4 + b) * 1024), "v"(acc[a][b]) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials have reached the coherence point ...
+                __syncthreads();
+                if (t == 0) {
+                    __hip_atomic_store(flags + role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ... before the flag
+                    while (__hip_atomic_load(flags + (role ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+                    __hip_atomic_store(flags + (role ^ 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed: ready for the next launch
+                }
+                __syncthreads();
+                if (wm == role) {
+                    const char* src = ws + (size_t)(role ^ 1) * (PAIR_TILE_BYTES / 2) + slot;
+                    // two batches of 16 loads, each one round trip (a batch per accumulator row made eight dependent round trips of
+                    // ~2 us while all 234 workgroups exchange at once)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 p[16];
+                        asm volatile(
+                            "global_load_dwordx4 %0, %16, off sc1\n\t"
+                            "global_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
+                            "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\t"
+                            "global_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
+                            "global_load_dwordx4 %4, %17, off sc1\n\t"
+                            "global_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
+                            "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\t"
+                            "global_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
+                            "global_load_dwordx4 %8, %18, off sc1\n\t"
+                            "global_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
+                            "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\t"
+                            "global_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
+                            "global_load_dwordx4 %12, %19, off sc1\n\t"
+                            "global_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
+                            "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\t"
+                            "global_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
+                            "s_waitcnt vmcnt(0)"
+                            : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]),
+                              "=&v"(p[8]), "=&v"(p[9]), "=&v"(p[10]), "=&v"(p[11]), "=&v"(p[12]), "=&v"(p[13]), "=&v"(p[14]), "=&v"(p[15])
+                            : "v"(src + (h * 4 + 0) * 4096), "v"(src + (h * 4 + 1) * 4096), "v"(src + (h * 4 + 2) * 4096), "v"(src + (h * 4 + 3) * 4096)
+                            : "memory");
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) acc[h * 4 + a][b] += p[a * 4 + b];
+                    }
+                }
+            }
+        }
     } else if (nkt > 0) {
 #pragma unroll
         for (int p = 0; p < S - 1; ++p) {
@@ -744,6 +869,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                 load_frags4<BT, BN>(bfr, sb, wn * 64, lane);
 #pragma unroll
                 for (int h = 0; h < MI / 4; ++h) load_frags4<AT, BM>(af + 4 * h, sa, wm * (MI * 16) + h * 64, lane);
+                if constexpr (MI % 4 == 2) load_frags2<AT, BM>(af + MI - 2, sa, wm * (MI * 16) + (MI - 2) * 16, lane);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -782,6 +908,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                 load_frags4<BT, BN>(bfr, sb, wn * 64, lane);
 #pragma unroll
                 for (int h = 0; h < MI / 4; ++h) load_frags4<AT, BM>(af + 4 * h, sa, wm * (MI * 16) + h * 64, lane);
+                if constexpr (MI % 4 == 2) load_frags2<AT, BM>(af + MI - 2, sa, wm * (MI * 16) + (MI - 2) * 16, lane);
                 const int younger = min(S - 2, nkt - 2 - kt);   // tiles younger than kt+1 still allowed in flight
                 if (grp == 1 && kt + 1 < nkt) {
                     if (younger >= 2) wait_vmcnt<2 * LPT>();
@@ -826,6 +953,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
     }
     __syncthreads();
     constexpr bool F32_TILE = (EPI == WJ_EPI_ADD_F32 || EPI == WJ_EPI_ATOMIC_F32);
+    static_assert(BMT == 256 || EPI == WJ_EPI_ATOMIC_F32, "384-row tiles: the split-K weight-gradient epilogue (three 128-row chunks)");
     constexpr int RC = F32_TILE ? C_::RC_F32 : C_::RC_BF16;
     constexpr int CP = F32_TILE ? C_::CP_F32 : C_::CP_BF16;
     constexpr int NCHUNK = BM / RC;
@@ -838,7 +966,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int mrow = wm * ROWS_PER_WAVE + mi * 16;       // wave-uniform
-            if (mrow >= r_lo && mrow < r_lo + RC) {
+            if (mrow >= r_lo && mrow < r_lo + RC && (!pair || wm == role)) {     // (a K-split pair: this workgroup finishes the rows of its role only)
                 const int m = mrow - r_lo + i;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
@@ -927,6 +1055,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
             for (int ps = 0; ps < PASSES; ++ps) {
                 const int r = rr + RPP * ps, m = mh + r;
                 if (!(ncol && m < M)) continue;
+                if (pair && ((r_lo + r) >> 7) != role) continue;
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CP + c8 * 2);
                 long orow = m;
                 if constexpr (GATHER == 1) orow = crow[ps];
@@ -1046,7 +1175,6 @@ __global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_kernel(const bf16
 // launch.  Why: a lone wgrad has few output tiles (9-36), so filling 256 CUs needs split-K 7-28, and every K slice ends with a
 // 256 x 256 fp32 atomic tile -- at the chip-wide float-atomic rate (~1.3 TB/s) that epilogue was 35-50 % of each launch.  Grouped,
 // the tiles of all problems fill the chip with split-K 1-8: 3-4x fewer atomic bytes, K loops 3-8x longer.
-// Workgroup ranges of the problems are padded to multiples of 8 so that blockIdx % 8 still names the XCD inside a problem.
 struct GroupProblem {
     const bf16_t* A;
     const bf16_t* B;
@@ -1060,19 +1188,38 @@ struct GroupTable {
     int n;
 };
 
-template <int BN>
-__global__ __launch_bounds__(NT, BN == 256 ? 1 : 2) void gemm3_grouped_wgrad_kernel(GroupTable g) {
+template <int BN, int BMT = 256, int SCHED = 0>
+__global__ __launch_bounds__(NT, (BN == 256 || BMT == 384) ? 1 : 2) void gemm3_grouped_wgrad_kernel(GroupTable g) {
+    // XCD-grouped order over the WHOLE group (blocks b, b + 8, ... share an XCD and get a contiguous run of the group's work list:
+    // neighbours inside a problem, i.e. tiles that stream the same K slice).  No padding between problems: a group sized for the
+    // chip's resident slots must not spill a few workgroups into a second round.
+    const int gid = xcd_remap(blockIdx.x, gridDim.x);
     int q = 0;
 #pragma unroll 1
     for (int x = 1; x < g.n; ++x)
-        if ((int)blockIdx.x >= g.p[x].wg_begin) q = x;
+        if (gid >= g.p[x].wg_begin) q = x;
     const GroupProblem& P = g.p[q];
-    const int bid = blockIdx.x - P.wg_begin;
-    if (bid >= P.nwg) return;               // padding workgroup
+    const int bid = gid - P.wg_begin;
     EpiArgs e;
     e.C = P.C; e.C2 = nullptr; e.bias = nullptr; e.aux = nullptr; e.colsum = nullptr; e.ldc = P.ldc; e.seg_rows = 1; e.seg_valid = 1;
     e.alpha = 1.f; e.rowmap = nullptr; e.sa = nullptr; e.sb = nullptr; e.lds_a = 0; e.lds_b = 0; e.q_out = nullptr; e.q_scales = nullptr; e.ld_q = 0;
-    gemm3_body<true, true, WJ_EPI_ATOMIC_F32, BN, 0, 0>(P.A, P.B, P.lda, P.ldb, P.M, P.N, P.K, P.tiles_n, P.split, P.kps, e, bid, P.nwg);
+    e.pair_ws = nullptr; e.pair_flags = nullptr;
+    gemm3_body<true, true, WJ_EPI_ATOMIC_F32, BN, SCHED, 0, BMT>(P.A, P.B, P.lda, P.ldb, P.M, P.N, P.K, P.tiles_n, P.split, P.kps, e, bid, P.nwg, true);
+}
+
+// K-split pairs (gemm3_body): which problems, and the scratch they need: [tiles][2] flags (padded to 4 KiB), then per tile and role
+// the accumulators of four waves (32 registers x 64 lanes x 16 B each).
+int pair_min_k() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("WJ_PAIR_MIN_K"); v = s ? atoi(s) : 1536; }     // WJ_PAIR_MIN_K=1000000: pairs off (A/B runs)
+    return v;
+}
+long pair_ws_need(int tiles) { return 4096L * ((tiles * 8 + 4095) / 4096) + (long)tiles * PAIR_TILE_BYTES; }
+bool pair_shape(const wj_gemm_args* a) {
+    if (a->a_trans || a->b_trans || a->rowmap || a->colsum || a->split_k > 1 || a->epilogue != WJ_EPI_BF16) return false;
+    if (a->N % 256 != 0 || a->K % 256 != 0 || a->K < pair_min_k()) return false;
+    const int tiles = ((a->M + BM - 1) / BM) * (a->N / 256);
+    return tiles > 32 && tiles <= 128;            // 2 x tiles workgroups fit the chip in one round (<= 32 tiles would want a deeper split)
 }
 
 template <bool AT, bool BT, int EPI, int BN, int SCHED, int GATHER = 0>
@@ -1081,17 +1228,28 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
     int split = a->split_k < 1 ? 1 : a->split_k;
     int kps = ((a->K + split - 1) / split + 63) / 64 * 64;
     split = (a->K + kps - 1) / kps;
+    bool pair = false;
+    if constexpr (SCHED == 2 && EPI == WJ_EPI_BF16 && GATHER == 0 && BN == 256) {
+        pair = pair_shape(a) && a->workspace && a->workspace_bytes >= pair_ws_need(tiles_m * tiles_n) && !((uintptr_t)a->workspace & 255);
+        if (pair) { split = 2; kps = a->K / 2; }
+    }
     EpiArgs e;
     e.C = a->C; e.C2 = a->epilogue == WJ_EPI_BIAS_GELU ? nullptr : a->C2; e.bias = (const float*)a->bias; e.aux = a->aux; e.ldc = a->ldc; e.colsum = a->colsum;
     e.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1; e.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     e.alpha = a->alpha;
     e.rowmap = a->rowmap;
     e.sa = nullptr; e.sb = nullptr; e.lds_a = 0; e.lds_b = 0; e.q_out = nullptr; e.q_scales = nullptr; e.ld_q = 0;
+    e.pair_ws = nullptr; e.pair_flags = nullptr;
+    if (pair) {
+        e.pair_flags = (unsigned*)a->workspace;
+        e.pair_ws = (float*)((char*)a->workspace + 4096L * ((tiles_m * tiles_n * 8 + 4095) / 4096));
+    }
     auto kern = gemm3_kernel<AT, BT, EPI, BN, SCHED, GATHER>;
     constexpr int lds = Cfg<BN>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
-    const int nwg = tiles_m * tiles_n * split;
+    // pairs: every XCD gets both roles of its run of tiles (ceil(tiles / 8) of each; spare workgroups leave at once)
+    const int nwg = pair ? 16 * ((tiles_m * tiles_n + 7) / 8) : tiles_m * tiles_n * split;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), lds, s, (const bf16_t*)a->A, (const bf16_t*)a->B, (long)a->lda,
                        (long)a->ldb, a->M, a->N, a->K, tiles_n, split, kps, e);
     WJ_CHECK_LAUNCH();
@@ -1170,6 +1328,7 @@ int launch_fp8(const wj_gemm_fp8_args* a, hipStream_t s) {
     e.seg_rows = 1; e.seg_valid = 1; e.alpha = 1.f; e.rowmap = nullptr;
     e.sa = (const uint32_t*)a->scale_a; e.sb = (const uint32_t*)a->scale_b; e.lds_a = a->ld_scale_a; e.lds_b = a->ld_scale_b;
     e.q_out = (unsigned char*)a->q_out; e.q_scales = (uint32_t*)a->q_scales; e.ld_q = a->ld_q_scale;
+    e.pair_ws = nullptr; e.pair_flags = nullptr;
     auto kern = gemm3_kernel<false, false, EPI, 256, 3, 0>;
     constexpr int lds = Cfg<256>::LDS_BYTES;     // 135168 >= ring (128 KiB) + two parities of block scales (4 KiB)
     static_assert(lds >= 131072 + 4096, "LDS budget of the MX fp8 loop");
@@ -1199,14 +1358,15 @@ extern "C" int wj_gemm_mxfp8(const wj_gemm_fp8_args* a, void* stream) {
     }
 }
 
-template <int BN>
+template <int BN, int BMT = 256, int SCHED = 0>
 int launch_grouped(const wj_wgrad_group_args* a, hipStream_t s) {
+    constexpr int BM = BMT;
     GroupTable g;
     g.n = a->n;
     long tiles_total = 0;
     for (int x = 0; x < a->n; ++x)
         tiles_total += (long)((a->M[x] + BM - 1) / BM) * ((a->N[x] + BN - 1) / BN);
-    const int slots = BN == 256 ? 256 : 512;                         // co-resident workgroups of this tile variant
+    const int slots = (BN == 256 || BMT == 384) ? 256 : 512;         // co-resident workgroups of this tile variant
     int begin = 0;
     for (int x = 0; x < a->n; ++x) {
         GroupProblem& P = g.p[x];
@@ -1224,10 +1384,10 @@ int launch_grouped(const wj_wgrad_group_args* a, hipStream_t s) {
         P.split = (P.K + P.kps - 1) / P.kps;
         P.nwg = tiles * P.split;
         P.wg_begin = begin;
-        begin += (P.nwg + 7) / 8 * 8;
+        begin += P.nwg;
     }
-    auto kern = gemm3_grouped_wgrad_kernel<BN>;
-    constexpr int lds = Cfg<BN>::LDS_BYTES;
+    auto kern = gemm3_grouped_wgrad_kernel<BN, BMT, SCHED>;
+    constexpr int lds = Cfg<BN, BMT>::LDS_BYTES;
     static int attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return WJ_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(begin), dim3(NT), lds, s, g);
@@ -1238,14 +1398,28 @@ int launch_grouped(const wj_wgrad_group_args* a, hipStream_t s) {
 extern "C" int wj_wgrad_grouped(const wj_wgrad_group_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || a->n < 1 || a->n > GROUP_MAX) return WJ_ERR_ARG;
-    bool wide = true;
+    bool wide = true, m384 = true;
     for (int x = 0; x < a->n; ++x) {
         if (!a->A[x] || !a->B[x] || !a->C[x] || a->M[x] <= 0 || a->N[x] <= 0 || a->K[x] <= 0) return WJ_ERR_ARG;
         if ((a->M[x] & 7) || (a->N[x] & 7) || (a->lda[x] & 7) || (a->ldb[x] & 7) || (a->ldc[x] & 3)) return WJ_ERR_ARG;
         if (((uintptr_t)a->A[x] | (uintptr_t)a->B[x] | (uintptr_t)a->C[x]) & 15) return WJ_ERR_ARG;
         wide = wide && a->N[x] % 256 == 0;
+        m384 = m384 && a->M[x] % 384 == 0 && a->N[x] % 128 == 0;
     }
-    return wide ? launch_grouped<256>(a, (hipStream_t)stream) : launch_grouped<128>(a, (hipStream_t)stream);
+    if (wide) return launch_grouped<256>(a, (hipStream_t)stream);
+    // every problem a multiple of 384 rows x 128 columns (the predictor: d = 384): the 384 x 128 tile has no half-empty row tiles
+    // (WJ_WGRAD_384=0: the 256 x 128 tile, round 4; =2: the ping-pong schedule on the 384 x 128 tile)
+    static int m384_mode = -1;
+    if (m384_mode < 0) { const char* v = getenv("WJ_WGRAD_384"); m384_mode = v ? atoi(v) : 1; }
+    if (m384 && m384_mode == 1) return launch_grouped<128, 384, 0>(a, (hipStream_t)stream);
+    if (m384 && m384_mode == 2) return launch_grouped<128, 384, 1>(a, (hipStream_t)stream);
+    return launch_grouped<128>(a, (hipStream_t)stream);
+}
+
+// scratch bytes wj_gemm_bf16 can use for this problem (0: none) -- wj_workspace_bytes("wj_gemm_bf16", args)
+int64_t wj_gemm_ws_bytes(const wj_gemm_args* a) {
+    if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || !pair_shape(a)) return 0;
+    return pair_ws_need(((a->M + BM - 1) / BM) * (a->N / 256));
 }
 
 extern "C" int wj_gemm_set_variant(int variant) {

@@ -557,6 +557,7 @@ extern "C" int wj_struct_size(const char* name) {
     return -1;
 }
 
+int64_t wj_gemm_ws_bytes(const wj_gemm_args* a);              // csrc/gemm.hip
 int64_t wj_conv0_fwd_ws_bytes(const wj_conv0_fwd_args* a);   // csrc/conv0.hip
 int64_t wj_conv0_bwd_ws_bytes(const wj_conv0_bwd_args* a);
 int64_t wj_rir_conv_ws_bytes(const wj_rir_conv_args* a);      // csrc/scene.hip
@@ -565,6 +566,7 @@ int64_t wj_mse_groups_ws_bytes(const wj_mse_groups_args* a);  // csrc/denoise.hi
 
 extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     if (!fn || !args) return -1;
+    if (!strcmp(fn, "wj_gemm_bf16")) return wj_gemm_ws_bytes((const wj_gemm_args*)args);
     if (!strcmp(fn, "wj_layernorm_bwd")) return 1536LL * 3 * ((const wj_ln_bwd_args*)args)->D * 4;
     if (!strcmp(fn, "wj_attn_bwd")) {
         const wj_attn_bwd_args* a = (const wj_attn_bwd_args*)args;
@@ -580,7 +582,7 @@ extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     if (!strcmp(fn, "wj_rir_convolve")) return wj_rir_conv_ws_bytes((const wj_rir_conv_args*)args);
     if (!strcmp(fn, "wj_snr_mix")) return wj_snr_mix_ws_bytes((const wj_snr_mix_args*)args);
     if (!strcmp(fn, "wj_mse_groups")) return wj_mse_groups_ws_bytes((const wj_mse_groups_args*)args);
-    static const char* const none[] = {"wj_gemm_bf16", "wj_layernorm_fwd", "wj_colsum_bf16", "wj_colsum_f32", "wj_attn_fwd", "wj_gelu_bwd_bf16",
+    static const char* const none[] = {"wj_layernorm_fwd", "wj_colsum_bf16", "wj_colsum_f32", "wj_attn_fwd", "wj_gelu_bwd_bf16",
         "wj_conv_weight_layout", "wj_add_pos", "wj_mask_gather_rows", "wj_mask_scatter_fill_pos", "wj_mask_scatter_fill_pos_bwd",
         "wj_unmask_rows_f32", "wj_instnorm_accumulate", "wj_instnorm_mean", "wj_ema_update", "wj_adamw_step", "wj_cast_f32_to_bf16",
         "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir", "wj_transpose_bf16", "wj_colsum_f32_group", "wj_rccl_bucket_allreduce_launch", "wj_rccl_bucket_allreduce_wait"};

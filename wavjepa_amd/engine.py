@@ -331,6 +331,9 @@ class JepaEngine:
         # batched transpose, wj_transpose_bf16): the persistent eight-phase kernel instead of the col-form 256 x 128 schedule.
         # WJ_WT_DGRAD=0 keeps the col-form dgrads (A/B runs).
         self.wt_dgrad = _os.environ.get("WJ_WT_DGRAD", "1") != "0"
+        # K-split pairs for the student's 117-tile GEMMs (WJ_PAIR_SPLIT=0: off): scratch handed to the main-stream launches of that stack
+        self.pair_split = _os.environ.get("WJ_PAIR_SPLIT", "1") != "0"
+        self.pair_ws = None
         self._conv_w_fresh = False
         self.defer_folds = _os.environ.get("WJ_DEFER_FOLDS", "1") != "0"
         self._folds = []
@@ -395,6 +398,7 @@ class JepaEngine:
     def _bind_wt(self) -> None:
         """W^T shadows: one more bf16 buffer with the parameter layout, every 2-D transformer weight stored transposed at its own offset."""
         f = self.flat
+        self._enc_ids = {id(w) for w in self.enc_layers}       # the student's layers (their main-stream launches carry the K-split scratch)
         self.p16t = None
         self._wt_tables = {}                   # (student weights, predictor weights) that take the row form -> (table, n_mats, n_tiles)
         self._wt_need = ((), ())               # ... of the step being run (set by the forward from its row counts)
@@ -418,11 +422,22 @@ class JepaEngine:
         col form on the 256 x 128 schedule (234 workgroups) against 64 / 49 / 24 us in row form on the one-tile eight-phase schedule."""
         return -(-M // 256) * (N // 256 + (1 if N % 256 else 0)) >= 256
 
-    def _wt_keys(self, M: int, D: int):
-        """The weights of a stack of width D whose dgrad over M rows takes the row form (output widths: w2 -> 4D, the others -> D)."""
+    PAIR_TILES = (33, 128)      # output tiles of a problem that runs as K-split pairs (csrc/gemm.hip: pair_shape)
+
+    def _pair_pays(self, M: int, N: int, K: int) -> bool:
+        """A row-form GEMM [M, N] over K that the library runs as K-split pairs when it is handed scratch (wj_gemm_args.workspace): the
+        ragged student's N = 768 products (117 tiles for 256 CUs).  Measured (tools/gemm_small.py, operands not cache-resident):
+        K = 3072 74 -> 60 us, K = 2304 58 -> 48 us, against 75 / 57 us for the col-form dgrad; K = 768 loses (27 -> 30 us)."""
+        tiles = -(-M // 256) * (N // 256)
+        return self.pair_split and N % 256 == 0 and K % 256 == 0 and K >= 1536 and self.PAIR_TILES[0] <= tiles <= self.PAIR_TILES[1]
+
+    def _wt_keys(self, M: int, D: int, pairs: bool = False):
+        """The weights of a stack of width D whose dgrad over M rows takes the row form (output widths: w2 -> 4D, the others -> D;
+        contraction lengths: wqkv 3D, wo D, w1 4D, w2 D).  pairs: the stack's launches carry the K-split scratch (the student)."""
         if not self.wt_dgrad:
             return ()
-        return tuple(k for k, n_out in (("wqkv", D), ("wo", D), ("w1", D), ("w2", 4 * D)) if self._row_form_pays(M, n_out))
+        return tuple(k for k, n_out, k_in in (("wqkv", D, 3 * D), ("wo", D, D), ("w1", D, 4 * D), ("w2", 4 * D, D))
+                     if self._row_form_pays(M, n_out) or (pairs and self._pair_pays(M, n_out, k_in)))
 
     def _alloc_conv_weights(self) -> None:
         C = self.C
@@ -461,7 +476,8 @@ class JepaEngine:
         """out[M, N] = x[M, K] . W^T (+ bias, epilogue): the bf16 GEMM, or in fp8 mode (eligible K) quantise x and run the MX fp8 GEMM."""
         w8 = self._w8.get(w_ptr) if self.fp8 else None
         if w8 is None:
-            ops.gemm(x, w_ptr, out, C2=C2, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=epilogue)
+            ops.gemm(x, w_ptr, out, C2=C2, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=epilogue,
+                     workspace=self.pair_ws if stack == "enc" else None)       # K-split pairs: main-stream launches only
             return
         q, sc = self._a8[stack]
         ops.quantize_mxfp8(x, q, sc, M=M, K=K, ldx=K, ldq=K, ld_scale=M)
@@ -583,6 +599,10 @@ class JepaEngine:
                 if l > 0:
                     t, p = self._rows(Nc * self.P[l], C, bf)
                     self.dpre.append(t); self.dpre_ptr.append(p)
+        if self.pair_split and self.pair_ws is None:
+            # zero-filled ONCE; the library keeps its flags at zero between launches.  Sized for the largest problem that splits.
+            self.pair_ws = torch.zeros(ops.workspace_bytes("wj_gemm_bf16", M=256 * (self.PAIR_TILES[1] // 2), N=512, K=2048, lda=2048, ldb=2048,
+                                                           ldc=512, epilogue=ops.EPI_BF16), dtype=torch.uint8, device=dev)
         self.gn_stats = _empty(2, Nc, C, dtype=f32, device=dev)
         taps = c.in_channels * c.conv_spec[0][1]
         conv0_dims = dict(N=N, C_in=c.in_channels, C=C, k=c.conv_spec[0][1], L_out=self.L[0])      # per stream: N clips a call
@@ -736,7 +756,7 @@ class JepaEngine:
 
     def set_wt_need(self, rows_enc: int, rows_dec: int) -> None:
         """Which weights' dgrads run in row form this step (decided per stack from its row count)."""
-        self._wt_need = (self._wt_keys(rows_enc, self.cfg.d_enc), self._wt_keys(rows_dec, self.cfg.d_dec) if self.dec_layers else ())
+        self._wt_need = (self._wt_keys(rows_enc, self.cfg.d_enc, pairs=True), self._wt_keys(rows_dec, self.cfg.d_dec) if self.dec_layers else ())
         self._wt_live = {id(w): self._wt_need[0] for w in self.enc_layers}
         self._wt_live.update({id(w): self._wt_need[1] for w in self.dec_layers})
 
@@ -768,7 +788,8 @@ class JepaEngine:
         """out[M, N] = dY[M, K] . W   (W = the layer's `key` weight, stored [K][N] as nn.Linear keeps it): against the W^T shadow as a
         row-form GEMM, or (WJ_WT_DGRAD=0, widths that are not multiples of 64) against W itself in col form."""
         if self.wt_dgrad and key in self._wt_live.get(id(w), ()):
-            ops.gemm(dY, getattr(w, key + "T"), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+            ops.gemm(dY, getattr(w, key + "T"), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+                     workspace=self.pair_ws if id(w) in self._enc_ids else None, **kw)
         else:
             ops.gemm(dY, getattr(w, key), out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_trans=1, **kw)
 

@@ -107,7 +107,7 @@ def require_gpu() -> None:
 
 def workspace_bytes(fn: str, **dims) -> int:
     """Scratch bytes entry point `fn` needs for the given dimensions (fields of its argument struct), from the library."""
-    struct_name = {"wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
+    struct_name = {"wj_gemm_bf16": "wj_gemm_args", "wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
                    "wj_conv0_gn_gelu_bwd": "wj_conv0_bwd_args", "wj_masked_mse": "wj_mse_args", "wj_grad_sumsq": "wj_sumsq_args",
                    "wj_rir_convolve": "wj_rir_conv_args", "wj_snr_mix": "wj_snr_mix_args", "wj_mse_groups": "wj_mse_groups_args"}[fn]
     a = STRUCTS[struct_name]()
@@ -120,11 +120,13 @@ def workspace_bytes(fn: str, **dims) -> int:
 def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, a_trans: int = 0,
          b_trans: int = 0, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, aux: Ptr = None, split_k: int = 1,
          seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, colsum: Ptr = None, rowmap: Ptr = None,
-         stream: Optional[int] = None) -> None:
+         workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
+    """workspace: a zero-initialised byte tensor the library may use for K-split pairs (see include/wavjepa_hip.h: wj_gemm_args)."""
     _run("wj_gemm_bf16", "wj_gemm_args", stream, A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), aux=_p(aux), colsum=_p(colsum),
          rowmap=_p(rowmap),
          lda=lda, ldb=ldb, ldc=ldc, M=M, N=N, K=K, a_trans=a_trans, b_trans=b_trans, epilogue=epilogue, split_k=split_k,
-         seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha)
+         seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha, workspace=_p(workspace),
+         workspace_bytes=0 if workspace is None else workspace.numel() * workspace.element_size())
 
 
 def gemm_mxfp8(A8: Ptr, B8: Ptr, scale_a: Ptr, scale_b: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
