@@ -320,7 +320,11 @@ def main():
         threading.Thread(target=run, daemon=True).start()
 
     watchdog()
+    if args.emulate_allreduce:
+        os.environ["WJ_EMULATE_ALLREDUCE"] = "1"
     rank, local, world = init_distributed()
+    if args.emulate_allreduce and world != 1:
+        raise SystemExit("--emulate-allreduce rehearses the collective's footprint on ONE GPU; with N > 1 ranks the real all-reduce runs")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     device = torch.device("cuda", local)
@@ -412,7 +416,7 @@ def main():
         step_idx += 1
     sync()
     note("timed region")
-    runner.reducer.timing = runner.reducer.active
+    runner.reducer.timing = runner.reducer.active or runner.reducer.emulate
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = runner.step(source.next_batch(), step_idx)
@@ -554,7 +558,13 @@ def main():
             # the same step computed with the reference's dense shapes (WJ_RAGGED=0 equivalent), this run
             "dense_ms_per_step": None if dense_ms is None else round(dense_ms, 2),
             "dense_clips_per_s": None if dense_ms is None else round(args.clips_per_gpu * world / (dense_ms / 1000), 1),
-            "allreduce": allreduce,
+            "allreduce": None if runner.reducer.emulate else allreduce,
+            # --emulate-allreduce (one GPU): NOT a collective -- a paced in-place copy kernel on the CUs a data-parallel run keeps free
+            # stands in for the all-reduce's CU + HBM share; ms_per_step of this line is then the step WITH that load beside the backward
+            "allreduce_emulated": None if not runner.reducer.emulate else dict(
+                allreduce, emulation=True, workgroups=runner.reducer._emu_wgs, assumed_busbw_gbps=runner.reducer._emu_gbps or None,
+                assumed_world=runner.reducer._emu_world,
+                note="one GPU; a copy kernel reads and rewrites every gradient bucket twice on a communication stream; nothing crosses xGMI"),
             "replicas_equal": replicas_equal, "param_checksum": [float(v) for v in checksum.tolist()],
             "final_loss": round(loss, 5),
             "peak_hbm_gb": round(peak_timed_gb, 1),                     # warm-up + timed region (the arena follows the ragged row counts)

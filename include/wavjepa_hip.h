@@ -356,6 +356,21 @@ typedef struct {
 } wj_spin_args;
 int wj_spin(const wj_spin_args*, void* stream);
 
+/* MEASUREMENT AID, not a collective: the on-GPU footprint of an all-reduce of `bytes` bytes at `buf`, for rehearsing on ONE GPU what
+ * the gradient all-reduce of a data-parallel run (train.py:174-179) takes away from the kernels that run beside it.  `workgroups`
+ * resident workgroups of 512 threads (RCCL runs one per channel; the CUs a data-parallel run keeps free of persistent GEMM workgroups)
+ * read and rewrite the buffer IN PLACE `passes` times (2 = the reduce-scatter and all-gather legs: 2 x bytes read and written; the
+ * values are unchanged), paced so that the launch lasts at least `min_ticks` ticks of the 100 MHz clock (bytes over an assumed bus
+ * bandwidth; 0 = as fast as those CUs go).  No data leaves the GPU; nothing about xGMI is measured. */
+typedef struct {
+    void* buf;
+    int64_t bytes;       /* multiple of 16 */
+    int64_t min_ticks;
+    int32_t workgroups;  /* 1 .. 256 */
+    int32_t passes;      /* 1 .. 8 */
+} wj_collective_footprint_args;
+int wj_collective_footprint(const wj_collective_footprint_args*, void* stream);
+
 /* buf[rows[i]][0 .. row_bytes) = 0 for i < n_rows (restores the all-zero state of a sparse gradient buffer) */
 typedef struct {
     void* buf;
@@ -417,7 +432,9 @@ typedef struct {
 int wj_mask_scatter_fill_pos(const wj_scatter_fill_args*, void* stream);
 
 /* Backward of the above: dtok[b*T+t] = sum_g d_in[(b*G+g)][t] (f32);  rows with inv >= 0 go to d_ctx_feats (bf16),
- * the others are summed into d_mask_token (f32, atomic).
+ * the others are summed into d_mask_token (f32, atomic) -- or, with `partials` (wj_workspace_bytes bytes: one row of D floats per
+ * workgroup, wj_scatter_fill_bwd_partial_rows(B, T) rows), left as partial rows whose column sums the caller adds to d_mask_token
+ * (wj_colsum_f32 / wj_colsum_f32_group): no float atomics, bit-reproducible.  G <= 15.
  * Ragged form (rowmap != NULL): d_in is packed; rowmap[(b*G+g)*T + t] = its row for that token or -1 (not visible:
  * contributes nothing). */
 typedef struct {
@@ -425,10 +442,13 @@ typedef struct {
     const int32_t* inv;
     const int32_t* rowmap;   /* optional int32 [B*G*T]: ragged form */
     void* d_ctx_feats;
-    float* d_mask_token;
+    float* d_mask_token;     /* NULL: the mask-token gradient is not wanted */
+    float* partials;         /* optional, see above (d_mask_token must still be non-NULL to request the gradient) */
     int32_t B, T, D, G;
 } wj_scatter_fill_bwd_args;
 int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args*, void* stream);
+/* rows of `partials` the launch writes; no stream, no device work */
+int wj_scatter_fill_bwd_partial_rows(int B, int T);
 
 /* dst[m][:] = inv[m] >= 0 ? src[inv[m]][:] : 0   for all M rows (dgrad of the gather: the gradient w.r.t. the
  * student encoder output / the local features is zero on non-context rows, jepa.py:399).  src is bf16 (or f32 when

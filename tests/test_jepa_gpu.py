@@ -507,6 +507,31 @@ def test_bench_one_rank_gradient_buckets_through_the_librarys_rccl_binding():
     assert a["param_checksum"][1] == pytest.approx(b["param_checksum"][1], rel=1e-6)
 
 
+def test_bench_emulated_allreduce_footprint_on_one_gpu():
+    """bench.py --emulate-allreduce (one GPU, no process group): the bucket hooks fire from the backward, a paced copy kernel stands in
+    for every bucket's all-reduce on a communication stream, the optimiser waits for it; the loss is that of the plain run (the
+    stand-in rewrites the gradients unchanged), and the line reports the rehearsal under `allreduce_emulated`, never under `allreduce`."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for emu in (False, True):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--clips-per-gpu", "16", "--dense-steps", "0",
+               "--no-cpu-baseline", "--no-profile", "--seed", "77"] + (["--emulate-allreduce"] if emu else [])
+        env = dict(os.environ, WJ_EMULATE_BUSBW_GBPS="300")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        rc, out, err = launch.run(cmd, cwd=root, env=env, timeout=300)
+        assert rc == 0, err[-4000:]
+        lines[emu] = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    a, b = lines[False], lines[True]
+    assert a["allreduce_emulated"] is None and b["allreduce"] is None
+    e = b["allreduce_emulated"]
+    assert e["emulation"] is True and e["buckets"] >= 2 and e["workgroups"] == 32 and e["assumed_busbw_gbps"] == 300.0
+    assert e["backward_window_ms"] > 0 and e["exposed_ms"] >= 0
+    assert abs(a["final_loss"] - b["final_loss"]) < 2e-4 * abs(a["final_loss"]), (a["final_loss"], b["final_loss"])
+
+
 def test_bench_two_ranks_share_the_gpu_over_gloo():
     """The N = 2 launch of the bench end to end on the 1-GPU box: RCCL refuses two ranks on one device, so the collectives go over
     gloo (WJ_DIST_BACKEND, a development switch of init_distributed); everything else -- per-rank sources, broadcast, bucketed

@@ -882,6 +882,19 @@ def test_token_plumbing(ops):
     dsum = d_in.reshape(B, G, T, D).sum(1)
     assert relerr(dfe.float(), dsum[~ctx_mask]) < 4e-3
     assert relerr(dmt, dsum[ctx_mask].sum(0)) < 1e-5
+    # the mask-token gradient as partial rows (no atomics) + a column-sum fold: the same bf16 rows, the same sums, bit-identical reruns
+    nrows = ops.scatter_fill_bwd_partial_rows(B, T)
+    assert ops.workspace_bytes("wj_mask_scatter_fill_pos_bwd", B=B, T=T, D=D, G=G) == nrows * D * 4
+    outs = []
+    for _ in range(2):
+        part = torch.full((nrows, D), float("nan"), device=dev())
+        dfe2 = torch.zeros(n, D, dtype=torch.bfloat16, device=dev())
+        dmt2 = torch.zeros(D, device=dev())
+        ops.mask_scatter_fill_pos_bwd(d_in, inv, dfe2, dmt2, B=B, T=T, D=D, G=G, partials=part)
+        assert float(dmt2.abs().max()) == 0.0 and torch.equal(dfe2, dfe)
+        ops.colsum_f32_group([(part, D, nrows, D, dmt2, None, None, D)])
+        outs.append(dmt2)
+    assert relerr(outs[0], dsum[ctx_mask].sum(0)) < 1e-5 and torch.equal(outs[0], outs[1])
 
     back = torch.empty(B * T, D, device=dev())
     ops.unmask_rows_f32(feats, inv, back, M=B * T, D=D)
@@ -1153,3 +1166,23 @@ def test_gelu_backward_kernel_on_every_bf16_input(ops):
         bad = ok & (ulp > 1) & ~near
         assert not bool(bad.any()), (scale, vals[bad][:8].tolist(), got[bad][:8].tolist(), want[bad][:8].tolist())
         assert float(((ulp > 0) & ok).float().sum() / ok.float().sum()) < 0.02
+
+
+def test_collective_footprint_measurement_aid(ops):
+    """bench.py --emulate-allreduce: the stand-in for an all-reduce's on-GPU footprint rereads and rewrites the bucket in place -- the
+    values must come back unchanged (ragged size, few / many workgroups), and a paced launch lasts at least its pace."""
+    n = 3_000_003 * 4
+    x = rnd(n, seed=90)
+    ref = x.clone()
+    for wgs, passes in ((32, 2), (1, 1), (256, 3)):
+        ops.collective_footprint(x, n * 4 - (n * 4) % 16, workgroups=wgs, passes=passes)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.collective_footprint(x, n * 4 - (n * 4) % 16, workgroups=32, passes=2, min_ticks=200_000)     # 2 ms of the 100 MHz clock
+    e1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and 1.9 < e0.elapsed_time(e1) < 4.0
+    with pytest.raises(Exception):
+        ops.collective_footprint(x, 24, workgroups=32)                       # not a multiple of 16 bytes

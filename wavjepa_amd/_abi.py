@@ -90,7 +90,8 @@ def _make_struct(name: str, fields):
 STRUCTS = {name: _make_struct(name, fields) for name, fields in _STRUCT_FIELDS.items()}
 _NO_STREAM_FUNCS = {"wj_abi_version": [], "wj_device_count": [], "wj_struct_size": [ctypes.c_char_p],
                     "wj_gemm_set_variant": [ctypes.c_int], "wj_gemm_set_persist_cus": [ctypes.c_int],
-                    "wj_ln_bwd_partial_rows": [ctypes.c_int, ctypes.c_int], "wj_rccl_unique_id": [ctypes.c_void_p],
+                    "wj_ln_bwd_partial_rows": [ctypes.c_int, ctypes.c_int], "wj_scatter_fill_bwd_partial_rows": [ctypes.c_int, ctypes.c_int],
+                    "wj_rccl_unique_id": [ctypes.c_void_p],
                     "wj_rccl_bucket_allreduce_init": [ctypes.c_void_p], "wj_rccl_bucket_allreduce_finalize": []}
 
 _lib = None

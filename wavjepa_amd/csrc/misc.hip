@@ -171,54 +171,78 @@ __global__ __launch_bounds__(256) void scatter_fill_rows_kernel(wj_scatter_fill_
     }
 }
 
-constexpr int SFB_ROWS = 64;  // rows per workgroup in the backward
+// Backward.  Round 4's form (64 rows per workgroup, a wave walking 16 rows one after the other: index load -> row-map load -> data
+// load, three dependent round trips per row, then 384 global float atomics per workgroup into the same 384 addresses) ran at
+// 1.4 TB/s.  Now a wave owns SFB_WROWS rows whose indices (inv, and the G row-map entries of each) are fetched up front by one load per
+// lane and handed round with readlane; the G x SFB_WROWS data loads then have no address dependence on each other.  The mask-token
+// gradient of a workgroup goes to a row of `partials` (no atomics; folded by wj_colsum_f32_group) when the caller gives one.
+constexpr int SFB_WROWS = 4;                 // rows per wave
+constexpr int SFB_ROWS = 4 * SFB_WROWS;      // rows per workgroup
 __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_bwd_args a) {
-    __shared__ float macc[1024];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int D = a.D, M = a.B * a.T;
-    for (int i = threadIdx.x; i < 1024; i += 256) macc[i] = 0.f;
-    __syncthreads();
+    __shared__ float macc[4][1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int D = a.D, M = a.B * a.T, G = a.G;
+    const int m0 = blockIdx.x * SFB_ROWS + wave * SFB_WROWS;
+    // lane l < SFB_WROWS * (G + 1): row r = l / (G + 1), slot u = l % (G + 1): u == G -> inv[m], else the (packed) input row of group u
+    int idx = -1;
+    {
+        const int r = lane / (G + 1), u = lane - r * (G + 1), m = m0 + r;
+        if (r < SFB_WROWS && m < M) {
+            if (u == G) {
+                idx = a.inv[m];
+            } else {
+                const int b = m / a.T, t = m - b * a.T;
+                const int row = (b * G + u) * a.T + t;
+                idx = a.rowmap ? a.rowmap[row] : row;          // ragged: packed row of this token, -1 = not visible
+            }
+        }
+    }
     f32x4 mt[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) mt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int r0 = blockIdx.x * SFB_ROWS;
-    for (int rr = wave; rr < SFB_ROWS; rr += 4) {
-        const int m = r0 + rr;
-        if (m >= M) break;
-        const int b = m / a.T, t = m - b * a.T;
-        const int dst = a.inv[m];
+#pragma unroll
+    for (int r = 0; r < SFB_WROWS; ++r) {
+        if (m0 + r >= M) break;
+        const int dst = __builtin_amdgcn_readlane(idx, r * (G + 1) + G);
+        f32x4 s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < G; ++g) {
+            const int row = __builtin_amdgcn_readlane(idx, r * (G + 1) + g);
+            if (row < 0) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (c < D) s[j] += *reinterpret_cast<const f32x4*>(a.d_in + (long)row * D + c);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int g = 0; g < a.G; ++g) {
-                    long row = ((long)b * a.G + g) * a.T + t;
-                    if (a.rowmap) row = a.rowmap[row];        // ragged: packed row of this token, -1 = not visible
-                    if (row >= 0) s += *reinterpret_cast<const f32x4*>(a.d_in + row * D + c);
-                }
                 if (dst >= 0) {
                     bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f2bf(s[e]);
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(s[j][e]);
                     *reinterpret_cast<bf16x4*>((bf16_t*)a.d_ctx_feats + (long)dst * D + c) = o;
                 } else {
-                    mt[j] += s;
+                    mt[j] += s[j];
                 }
             }
         }
     }
+    if (!a.d_mask_token) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = lane * 4 + 256 * j;
-        if (c < D) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&macc[c + e], mt[j][e]);
-        }
+        if (c < D) *reinterpret_cast<f32x4*>(&macc[wave][c]) = mt[j];
     }
     __syncthreads();
-    if (a.d_mask_token)
-        for (int c = threadIdx.x; c < D; c += 256) atomicAdd(a.d_mask_token + c, macc[c]);
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float v = (macc[0][c] + macc[1][c]) + (macc[2][c] + macc[3][c]);
+        if (a.partials) a.partials[(long)blockIdx.x * D + c] = v;
+        else atomicAdd(a.d_mask_token + c, v);
+    }
 }
 
 // dst[m] = inv[m] >= 0 ? src[inv[m]] : 0     (gradient of the mask gather, jepa.py:399; inv == NULL: identity)
@@ -552,7 +576,7 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
     WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args) WJ_SZ(wj_spin_args)
-    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args) WJ_SZ(wj_colsum_group_args) WJ_SZ(wj_rccl_init_args) WJ_SZ(wj_rccl_launch_args) WJ_SZ(wj_rccl_wait_args)
+    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args) WJ_SZ(wj_colsum_group_args) WJ_SZ(wj_rccl_init_args) WJ_SZ(wj_rccl_launch_args) WJ_SZ(wj_rccl_wait_args) WJ_SZ(wj_collective_footprint_args)
 #undef WJ_SZ
     return -1;
 }
@@ -567,6 +591,10 @@ int64_t wj_mse_groups_ws_bytes(const wj_mse_groups_args* a);  // csrc/denoise.hi
 extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     if (!fn || !args) return -1;
     if (!strcmp(fn, "wj_gemm_bf16")) return wj_gemm_ws_bytes((const wj_gemm_args*)args);
+    if (!strcmp(fn, "wj_mask_scatter_fill_pos_bwd")) {           // `partials`: one row of D floats per workgroup
+        const wj_scatter_fill_bwd_args* a = (const wj_scatter_fill_bwd_args*)args;
+        return (int64_t)wj_scatter_fill_bwd_partial_rows(a->B, a->T) * a->D * 4;
+    }
     if (!strcmp(fn, "wj_layernorm_bwd")) return 1536LL * 3 * ((const wj_ln_bwd_args*)args)->D * 4;
     if (!strcmp(fn, "wj_attn_bwd")) {
         const wj_attn_bwd_args* a = (const wj_attn_bwd_args*)args;
@@ -583,9 +611,9 @@ extern "C" int64_t wj_workspace_bytes(const char* fn, const void* args) {
     if (!strcmp(fn, "wj_snr_mix")) return wj_snr_mix_ws_bytes((const wj_snr_mix_args*)args);
     if (!strcmp(fn, "wj_mse_groups")) return wj_mse_groups_ws_bytes((const wj_mse_groups_args*)args);
     static const char* const none[] = {"wj_layernorm_fwd", "wj_colsum_bf16", "wj_colsum_f32", "wj_attn_fwd", "wj_gelu_bwd_bf16",
-        "wj_conv_weight_layout", "wj_add_pos", "wj_mask_gather_rows", "wj_mask_scatter_fill_pos", "wj_mask_scatter_fill_pos_bwd",
+        "wj_conv_weight_layout", "wj_add_pos", "wj_mask_gather_rows", "wj_mask_scatter_fill_pos",
         "wj_unmask_rows_f32", "wj_instnorm_accumulate", "wj_instnorm_mean", "wj_ema_update", "wj_adamw_step", "wj_cast_f32_to_bf16",
-        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir", "wj_transpose_bf16", "wj_colsum_f32_group", "wj_rccl_bucket_allreduce_launch", "wj_rccl_bucket_allreduce_wait"};
+        "wj_crop_normalize_bf16", "wj_zero_rows", "wj_spin", "wj_gemm_mxfp8", "wj_quantize_mxfp8", "wj_wgrad_grouped", "wj_resample_fir", "wj_transpose_bf16", "wj_colsum_f32_group", "wj_rccl_bucket_allreduce_launch", "wj_rccl_bucket_allreduce_wait", "wj_collective_footprint"};
     for (const char* n : none)
         if (!strcmp(fn, n)) return 0;
     return -1;
@@ -618,6 +646,50 @@ extern "C" int wj_spin(const wj_spin_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || a->ticks < 0 || a->ticks > (1LL << 32)) return WJ_ERR_ARG;
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, STREAM, (long)a->ticks);
+    WJ_CHECK_LAUNCH();
+    return WJ_OK;
+}
+
+// the footprint of a collective on its GPU (see the header): `passes` in-place read + rewrite sweeps by a few resident workgroups,
+// stretched to `min_ticks` of the 100 MHz clock by pacing every piece
+typedef __attribute__((ext_vector_type(4))) unsigned cf_u32x4;
+__global__ __launch_bounds__(512) void collective_footprint_kernel(cf_u32x4* __restrict__ buf, long n16, long min_ticks, int passes) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const long per = (n16 + gridDim.x - 1) / gridDim.x;
+    const long lo = per * blockIdx.x, hi = min(n16, lo + per);
+    constexpr long PIECE = 512 * 8;                        // 64 KiB per workgroup and piece
+    const long npieces = ((hi > lo ? hi - lo : 0) + PIECE - 1) / PIECE * passes;
+    long done = 0;
+    for (int ps = 0; ps < passes; ++ps)
+        for (long p0 = lo; p0 < hi; p0 += PIECE) {
+            cf_u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long i = p0 + u * 512 + threadIdx.x;
+                v[u] = cf_u32x4{0u, 0u, 0u, 0u};
+                if (i < hi) v[u] = __builtin_nontemporal_load(buf + i);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long i = p0 + u * 512 + threadIdx.x;
+                asm volatile("" : "+v"(v[u].x));           // (keeps the rewrite of an unchanged value from being dropped)
+                if (i < hi) __builtin_nontemporal_store(v[u], buf + i);
+            }
+            ++done;
+            if (min_ticks > 0) {
+                const unsigned long long due = (unsigned long long)(min_ticks * done / npieces);
+                while (__builtin_amdgcn_s_memrealtime() - t0 < due) __builtin_amdgcn_s_sleep(16);
+            }
+        }
+}
+
+extern "C" int wj_collective_footprint(const wj_collective_footprint_args* a, void* stream) {
+    WJ_CLEAR_STALE_ERROR();
+    if (!a || !a->buf || a->bytes <= 0 || (a->bytes & 15) || ((uintptr_t)a->buf & 15) || a->workgroups < 1 || a->workgroups > 256 ||
+        a->passes < 1 || a->passes > 8 || a->min_ticks < 0)
+        return WJ_ERR_ARG;
+    hipLaunchKernelGGL(collective_footprint_kernel, dim3(a->workgroups), dim3(512), 0, STREAM, (cf_u32x4*)a->buf, (long)(a->bytes / 16),
+                       (long)a->min_ticks, a->passes);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }
@@ -680,10 +752,12 @@ extern "C" int wj_mask_scatter_fill_pos(const wj_scatter_fill_args* a, void* str
     return WJ_OK;
 }
 
+extern "C" int wj_scatter_fill_bwd_partial_rows(int B, int T) { return (int)(((long)B * T + SFB_ROWS - 1) / SFB_ROWS); }
+
 extern "C" int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->d_in || !a->inv || !a->d_ctx_feats || a->B <= 0 || a->T <= 0 || a->D <= 0 || (a->D & 3) || a->D > 1024 ||
-        a->G <= 0)
+        a->G <= 0 || a->G > 15)              // (a wave's 4 rows x (G + 1) indices are fetched by one load per lane)
         return WJ_ERR_ARG;
     const int grid = (a->B * a->T + SFB_ROWS - 1) / SFB_ROWS;
     hipLaunchKernelGGL(scatter_fill_bwd_kernel, dim3(grid), dim3(256), 0, STREAM, *a);

@@ -76,6 +76,28 @@ class FlatGradAllReducer:
         self._comm_stream = None
         if self.direct:
             self._init_direct()
+        # WJ_EMULATE_ALLREDUCE=1 (bench.py --emulate-allreduce; one GPU, no process group): at every bucket hook a copy kernel confined
+        # to WJ_EMULATE_WORKGROUPS resident workgroups (default 32 = the CUs a data-parallel run keeps free) reads and rewrites the
+        # bucket twice on a communication stream (ops.collective_footprint), paced to WJ_EMULATE_BUSBW_GBPS (an ASSUMED all-reduce bus
+        # bandwidth; 0 = unpaced).  A rehearsal of the collective's CU + HBM share on this GPU -- nothing crosses xGMI, nothing is reduced.
+        self.emulate = (not self.active) and os.environ.get("WJ_EMULATE_ALLREDUCE", "0") == "1"
+        if self.emulate:
+            import torch
+            self._comm_stream = torch.cuda.Stream()
+            self._emu_wgs = int(os.environ.get("WJ_EMULATE_WORKGROUPS", "32"))
+            self._emu_gbps = float(os.environ.get("WJ_EMULATE_BUSBW_GBPS", "0"))
+            self._emu_world = int(os.environ.get("WJ_EMULATE_WORLD", "8"))
+
+    def _emulated_launch(self, view) -> None:
+        import torch
+        from . import ops
+        nbytes = view.numel() * 4
+        ticks = 0
+        if self._emu_gbps > 0:      # ring all-reduce: 2 (W - 1) / W x bytes over the bus bandwidth; ticks of the 100 MHz clock
+            ticks = int(2.0 * (self._emu_world - 1) / self._emu_world * nbytes / (self._emu_gbps * 1e9) * 1e8)
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        ops.collective_footprint(view.data_ptr(), nbytes - nbytes % 16, workgroups=self._emu_wgs, passes=2, min_ticks=ticks,
+                                 stream=self._comm_stream.cuda_stream)
 
     def _init_direct(self) -> None:
         import torch
@@ -123,7 +145,7 @@ class FlatGradAllReducer:
             self.handles.append(dist.all_reduce(self.module._flat.g32, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
 
     def hook(self, tag: str) -> None:
-        if not self.active:
+        if not (self.active or self.emulate):
             return
         flat = self.module._flat
         if self._ranges is None:
@@ -133,14 +155,16 @@ class FlatGradAllReducer:
             self._t_first = torch.cuda.Event(enable_timing=True)
             self._t_first.record()
         for lo, hi in self._ranges.get(tag, []):
-            if self.direct:
+            if self.emulate:
+                self._emulated_launch(flat.g32[lo:hi])
+            elif self.direct:
                 self._direct_launch(flat.g32[lo:hi])
             else:
                 self.handles.append(dist.all_reduce(flat.g32[lo:hi], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
 
     def wait(self) -> None:
         t_end = t_done = None
-        if self.timing and (self.handles or self.direct):
+        if self.timing and (self.handles or self.direct or self.emulate):
             import torch
             t_end, t_done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t_end.record()
@@ -149,6 +173,9 @@ class FlatGradAllReducer:
         if self.direct:
             from . import ops
             ops.rccl_bucket_allreduce_wait(self._comm_stream.cuda_stream)
+        if self.emulate:
+            import torch
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
         if t_done is not None:
             t_done.record()
             self.timeline.append((self._t_first, t_end, t_done))

@@ -1128,8 +1128,17 @@ class JepaEngine:
             dy, dyb, _ = self._layer_bwd(self.dec_layers[i], self.dec_acts[i], x_in, xb_in, dy, dyb, bw["dy"], Md, Dd, c.h_dec, N * G, plan.vis_u8,
                                          bw, i % bw["nbuf"], dseq, sub=self.tail if (rag and i == c.l_dec - 1) else None, bottom=i == 0)
         n_ctx = plan.n_ctx
-        ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
-                                      rowmap=plan.dec_map if rag else None)
+        # the mask-token gradient leaves the kernel as one partial row per workgroup, folded with the other deferred folds (round 4:
+        # 384 global float atomics per workgroup into the same 384 addresses)
+        sf_rows = ops.scatter_fill_bwd_partial_rows(N, T)
+        if self.defer_folds and Dd <= 2304 and sf_rows * Dd * 4 <= self._red_bytes:
+            ws = self._fold_slot()
+            ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
+                                          rowmap=plan.dec_map if rag else None, partials=ws)
+            self._folds.append((ws, Dd, sf_rows, Dd, f.gptr("mask_token"), None, None, Dd))
+        else:
+            ops.mask_scatter_fill_pos_bwd(dy, plan.inv, self.d_cf, f.gptr("mask_token"), B=N, T=T, D=Dd, G=G,
+                                          rowmap=plan.dec_map if rag else None)
         # encoder_to_decoder_mapper (rows = gathered context tokens)
         ops.colsum_bf16(self.d_cf, f.gptr("encoder_to_decoder_mapper.bias"), M=n_ctx, N=Dd, ldx=Dd)
         self._wgrad(self.d_cf, self.ctx_in, f.gptr("encoder_to_decoder_mapper.weight"), Dd, De, n_ctx)

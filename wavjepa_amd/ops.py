@@ -107,7 +107,7 @@ def require_gpu() -> None:
 
 def workspace_bytes(fn: str, **dims) -> int:
     """Scratch bytes entry point `fn` needs for the given dimensions (fields of its argument struct), from the library."""
-    struct_name = {"wj_gemm_bf16": "wj_gemm_args", "wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
+    struct_name = {"wj_gemm_bf16": "wj_gemm_args", "wj_mask_scatter_fill_pos_bwd": "wj_scatter_fill_bwd_args", "wj_layernorm_bwd": "wj_ln_bwd_args", "wj_attn_bwd": "wj_attn_bwd_args", "wj_conv0_gn_gelu_fwd": "wj_conv0_fwd_args",
                    "wj_conv0_gn_gelu_bwd": "wj_conv0_bwd_args", "wj_masked_mse": "wj_mse_args", "wj_grad_sumsq": "wj_sumsq_args",
                    "wj_rir_convolve": "wj_rir_conv_args", "wj_snr_mix": "wj_snr_mix_args", "wj_mse_groups": "wj_mse_groups_args"}[fn]
     a = STRUCTS[struct_name]()
@@ -329,6 +329,13 @@ def spin(ticks: int, stream: Optional[int] = None) -> None:
     _run("wj_spin", "wj_spin_args", stream, ticks=int(ticks))
 
 
+def collective_footprint(buf: Ptr, nbytes: int, *, workgroups: int = 32, passes: int = 2, min_ticks: int = 0,
+                         stream: Optional[int] = None) -> None:
+    """Measurement aid (bench.py --emulate-allreduce): the on-GPU footprint of an all-reduce of `nbytes` at `buf`, see the header."""
+    _run("wj_collective_footprint", "wj_collective_footprint_args", stream, buf=_p(buf), bytes=int(nbytes), min_ticks=int(min_ticks),
+         workgroups=int(workgroups), passes=int(passes))
+
+
 def zero_rows(buf: Ptr, rows: Ptr, *, n_rows: int, row_bytes: int, stream: Optional[int] = None) -> None:
     _run("wj_zero_rows", "wj_zero_rows_args", stream, buf=_p(buf), rows=_p(rows), n_rows=n_rows, row_bytes=row_bytes)
 
@@ -360,9 +367,15 @@ def mask_scatter_fill_pos(ctx_feats: Ptr, inv: Ptr, mask_token: Ptr, pos: Ptr, *
 
 
 def mask_scatter_fill_pos_bwd(d_in: Ptr, inv: Ptr, d_ctx_feats: Ptr, d_mask_token: Ptr, *, B: int, T: int, D: int, G: int,
-                              rowmap: Ptr = None, stream: Optional[int] = None) -> None:
+                              rowmap: Ptr = None, partials: Ptr = None, stream: Optional[int] = None) -> None:
+    """partials: scratch for one row of D floats per workgroup (scatter_fill_bwd_partial_rows(B, T) rows); the mask-token gradient is
+    then left there as partial rows for a column-sum fold instead of being added with float atomics."""
     _run("wj_mask_scatter_fill_pos_bwd", "wj_scatter_fill_bwd_args", stream, d_in=_p(d_in), inv=_p(inv), rowmap=_p(rowmap),
-         d_ctx_feats=_p(d_ctx_feats), d_mask_token=_p(d_mask_token), B=B, T=T, D=D, G=G)
+         d_ctx_feats=_p(d_ctx_feats), d_mask_token=_p(d_mask_token), partials=_p(partials), B=B, T=T, D=D, G=G)
+
+
+def scatter_fill_bwd_partial_rows(B: int, T: int) -> int:
+    return int(_abi.load().wj_scatter_fill_bwd_partial_rows(int(B), int(T)))
 
 
 def unmask_rows_f32(src: Ptr, inv: Ptr, dst: Ptr, *, M: int, D: int, src_is_f32: bool = False, dst_is_bf16: bool = False,

@@ -90,7 +90,7 @@ class StepRunner:
         self._first_step_done = False
         self.sectioned = hasattr(model, "_grads_ready_hook")      # JEPA: bucketed all-reduces launched from the backward's hooks
         if self.sectioned:
-            model._grads_ready_hook = self.reducer.hook if self.reducer.active else None
+            model._grads_ready_hook = self.reducer.hook if (self.reducer.active or self.reducer.emulate) else None
         oc = model.configure_optimizers()
         self.optimizer = oc["optimizer"]
         self.scheduler = oc["lr_scheduler"]["scheduler"]
