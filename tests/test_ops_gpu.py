@@ -1186,3 +1186,34 @@ def test_collective_footprint_measurement_aid(ops):
     assert torch.equal(x, ref) and 1.9 < e0.elapsed_time(e1) < 4.0
     with pytest.raises(Exception):
         ops.collective_footprint(x, 24, workgroups=32)                       # not a multiple of 16 bytes
+
+
+def test_gemm_persistent_counter_slots_are_recycled(ops):
+    """The persistent kernel keys its tile counters by stream (64 sets).  A host that keeps creating streams used to drop to the one-tile
+    schedule from the 65th stream on; idle streams' sets are now handed on (least recently used first).  80 streams, two launches each
+    into NaN-filled outputs: every result must equal the first stream's bits (a counter set shared by two live launches, or one that
+    was not back at zero, would skip or repeat tiles)."""
+    M, N, K = 8192, 2048, 256
+    A = rnd(M, K, dtype=torch.bfloat16, seed=31)
+    W = rnd(N, K, scale=0.08, dtype=torch.bfloat16, seed=32)
+    prev = ops.gemm_set_variant(4)
+    try:
+        ref = None
+        streams = [torch.cuda.Stream() for _ in range(80)]
+        outs = []
+        for st in streams:
+            C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                ops.gemm(A, W, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+                ops.gemm(A, W, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+            outs.append(C)
+            if len(outs) % 16 == 0:
+                torch.cuda.synchronize()             # earlier streams are idle: their counter sets may change hands
+        torch.cuda.synchronize()
+        ref = outs[0]
+        assert not bool(torch.isnan(ref.float()).any()) and relerr(ref.float(), A.float() @ W.float().t()) < 4e-3
+        for C in outs[1:]:
+            assert torch.equal(C.view(torch.int16), ref.view(torch.int16))
+    finally:
+        ops.gemm_set_variant(prev)

@@ -38,6 +38,10 @@ CLASSES = [   # (label, regex on the kernel name); first match wins
     ("colsum", r"colsum"),
     ("targets / loss", r"instnorm|mse_"),
     ("token plumbing", r"gather_rows|scatter_fill|unmask_rows|zero_rows|add_pos|crop_kernel|conv_w_kernel|gelu_bwd"),
+    # hipMemcpy blits: ~770 of them in a row at start-up (model.to(device) / the flat-buffer build copy every parameter; kernel trace,
+    # profiles/r05_copybuffer_trace.txt), 3 per step afterwards -- the class is divided by the step count like the others, so its
+    # "per step" figure is mostly that one-time burst and shrinks with the length of the run
+    ("hip memcpy blits (start-up burst / steps)", r"rocclr_copyBuffer"),
     ("framework (torch fills / copies / rng)", r"at::native|rocclr|hiprand"),
 ]
 

@@ -718,6 +718,9 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 struct SlotTable {
     std::mutex mu;
     std::unordered_map<hipStream_t, int> slots;
+    hipStream_t owner[SLOTS] = {};
+    unsigned long long last_use[SLOTS] = {};      // launch sequence number of the slot's latest launch (LRU order)
+    unsigned long long seq = 0;
     unsigned* base[32] = {};      // per device: g_sched_ctr is a __device__ symbol, every device has its own copy
 };
 SlotTable& table() {
@@ -862,10 +865,30 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
         }
         auto it = T.slots.find(s);
         if (it == T.slots.end()) {
-            if ((int)T.slots.size() >= SLOTS) return WJ_ERR_UNSUPPORTED;
-            it = T.slots.emplace(s, (int)T.slots.size()).first;
+            int fresh = (int)T.slots.size();
+            if (fresh >= SLOTS) {
+                // Every counter set has an owner: hand the least recently used one whose stream is idle to the newcomer.  A set is back at
+                // zero whenever no launch of its stream is in flight (the last pull of a launch resets it), so an idle stream's set can change
+                // hands; a host that recycles streams (a 65th distinct stream used to fall back to the one-tile kernel for the life of the
+                // process) now keeps the persistent schedule.  A retired stream handle answers hipStreamQuery with an error: idle as well.
+                fresh = -1;
+                unsigned long long best = ~0ull;
+                for (int x = 0; x < SLOTS; ++x) {
+                    if (T.last_use[x] >= best) continue;
+                    const hipError_t q = hipStreamQuery(T.owner[x]);
+                    (void)hipGetLastError();
+                    if (q == hipErrorNotReady) continue;           // work in flight on that stream: its counters may be live
+                    best = T.last_use[x];
+                    fresh = x;
+                }
+                if (fresh < 0) return WJ_ERR_UNSUPPORTED;           // 64 streams with persistent GEMMs in flight at once
+                T.slots.erase(T.owner[fresh]);
+            }
+            T.owner[fresh] = s;
+            it = T.slots.emplace(s, fresh).first;
         }
         slot = it->second;
+        T.last_use[slot] = ++T.seq;
     }
     unsigned* ctr = T.base[dev] + (size_t)slot * 8 * CTR_STRIDE;
     switch (a->epilogue) {
