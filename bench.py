@@ -74,8 +74,7 @@ def gemm_kernel_name(f) -> str:
     return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
 
 
-PMC_FILES = ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
-SERIAL_STATS_FILES = ["r04_bench_kernel_stats_serial.csv", "r03_bench_kernel_stats_serial.csv"]
+PMC_FILES = ["r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
 
 
 def pmc_traffic_path():
@@ -106,29 +105,35 @@ def pmc_traffic_for(name: str):
     return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
 
 
-def rocprof_serial_ms_for(name: str):
-    """Kernel time per step of a GEMM class in the newest committed `rocprofv3 --kernel-trace --stats` summary of this command with the
-    side stream serialised (profiles/rNN_bench_kernel_stats_serial.csv): (ms per step, file name) or (None, None).  Steps are counted
-    from the AdamW launches.  NOT measured by this run."""
-    import csv
+def gemm_class_patterns(name: str):
+    """Kernel-name patterns (rocprofv3 summary) of a GEMM class of the instrumented step, or None."""
     import re
     m = re.match(r"gemm_kernel<([NT])([NT]),(\w+)>", name)
-    path = next((os.path.join(ROOT, "profiles", f) for f in SERIAL_STATS_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-    if not m or path is None:
-        return None, None
+    if not m:
+        return None
     epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5}[m.group(3)]
     pn = 6 if m.group(3) == "BIAS_GELU" else epi
     pats = [f"gemm3_kernel<{'true' if m.group(1) == 'T' else 'false'}, {'true' if m.group(2) == 'T' else 'false'}, {epi},"]
     if m.group(1) == "N" and m.group(2) == "N":
         pats += [f"gemm_persist_kernel<{pn}>", f"gemm_persist_kernel<{pn},"]
-    steps, ns = 1, 0.0
-    with open(path, newline="") as fh:
-        for r in csv.DictReader(fh):
-            if "adamw_kernel" in r["Name"]:
-                steps = max(steps, int(r["Calls"]))
-            if any(p in r["Name"] for p in pats):
-                ns += float(r["TotalDurationNs"])
-    return (ns / 1e6 / steps if ns else None), os.path.basename(path)
+    return pats
+
+
+def committed_rocprof_serial(name: str, workload: str, clips_per_gpu: int):
+    """The class's rate in the COMMITTED `rocprofv3 --kernel-trace --stats` summary of this command with the side stream serialised
+    (profiles/r05_serial_meta.json, written by tools/serial_meta.py next to the CSV it describes: that run's own algorithmic flops of the
+    class over that run's own kernel time, with its commit and configuration).  Returned only when the committed run had this run's
+    workload and clips per GPU -- a cross-check from another box, labelled as such, never a judged metric."""
+    path = os.path.join(ROOT, "profiles", "r05_serial_meta.json")
+    if not os.path.exists(path):
+        return None
+    meta = json.load(open(path))
+    c = meta.get("classes", {}).get(name)
+    if c is None or meta.get("workload") != workload or int(meta.get("clips_per_gpu", -1)) != int(clips_per_gpu):
+        return None
+    return dict(frac=c["frac"], achieved_tflops=c["tflops"], kernel_ms_per_step=c["kernel_ms_per_step"], gflop_per_step=c["gflop_per_step"],
+                source=f"profiles/{meta['csv']} at commit {meta.get('commit', '?')} ({meta.get('steps')} steps, {meta.get('clips_per_gpu')} clips/GPU): "
+                       "committed summary of this command, NOT collected by this run")
 
 
 def profile_one_step(runner, source, step_idx: int):
@@ -504,13 +509,11 @@ def main():
             all_ms = sum(v["ms"] for v in gemms.values())
             all_fl = sum(v["flops"] for v in gemms.values())
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-            ser_ms, ser_file = (None, None) if fp8 else (optional("rocprof summary", lambda: rocprof_serial_ms_for(name)) or (None, None))
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 1), peak=peak, unit="TFLOP/s",
                             frac=round(ach / peak, 4),
-                            # the same class by KERNEL time: this run's algorithmic flops of the class over its kernel time per step in the
-                            # committed rocprofv3 summary of this command with the side stream serialised (no event bracket in it)
-                            frac_rocprof_serial=None if not ser_ms else round(c["flops"] / (ser_ms * 1e-3) / 1e12 / peak, 4),
-                            rocprof_serial_source=ser_file,
+                            # the same class by KERNEL time in the committed rocprofv3 summary (its own flops over its own kernel time; only when
+                            # that run had this run's configuration; a cross-check, not collected by this run)
+                            committed_rocprof_serial=None if fp8 else optional("rocprof summary", lambda: committed_rocprof_serial(name, args.workload, args.clips_per_gpu)),
                             traffic=None if fp8 else optional("pmc summary", lambda: pmc_traffic_for(name)),
                             traffic_source=None if fp8 or pmc_traffic_path() is None else
                             f"profiles/{os.path.basename(pmc_traffic_path())} (rocprofv3 --pmc passes of this command, committed; not collected by this run)",

@@ -267,7 +267,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Follows the 256^2 8-phase structure of the CDNA4 guide (cdna_hip_programming.md section 5), re-derived for this kernel's
 // fragment maps:
 //   * K tile = 64 deep: LDS rows are 128 B, so every global -> LDS request is a FULL 128-B line (the 32-deep tiles of the other
-//     schedules fetch 64-B half lines, which cost the L2 -> LDS path as much as whole lines: DESIGN.md section 4).
+//     schedules fetch 64-B half lines, which cost the L2 -> LDS path as much as whole lines: DESIGN_EXPERIMENTS.md, round 2).
 //   * LDS = 2 parities x [A 256 rows | B 256 rows] x 128 B = 128 KiB; 16-B chunk c of row r sits at chunk position
 //     c ^ ((r >> 1) & 7): conflict-free for the ds_read_b128 lane groups (swizzle on the per-lane SOURCE address of the LDS-DMA
 //     and again on the read).
