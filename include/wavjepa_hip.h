@@ -44,7 +44,10 @@ enum {
     WJ_EPI_ADD_F32 = 3,       /* C(f32)   = acc (+ aux(f32))                       (dgrad + residual-stream)   */
     WJ_EPI_ATOMIC_F32 = 4,    /* C(f32)  += alpha * acc   (atomic; split_k >= 1)   (wgrad into the grad buffer) */
     WJ_EPI_CONV_GELU = 5,     /* C(bf16)  = pre = bf16(acc); C2(bf16) = gelu(pre); rows (m % seg_rows) >= seg_valid -> 0 */
-    WJ_EPI_BIAS_GELU = 6      /* C(bf16)  = gelu(bf16(acc + bias))      (linear1 + nn.GELU where no backward follows: teacher) */
+    WJ_EPI_BIAS_GELU = 6,     /* C(bf16)  = gelu(bf16(acc + bias))      (linear1 + nn.GELU where no backward follows: teacher) */
+    WJ_EPI_MUL_GELU_GRAD_Z = 7 /* C(bf16) = bf16(acc) * gelu'(aux(bf16)), aux = the PRE-activation z at C's own rows / stride (evaluated here):
+                                  the sparse conv dgrad (rowmap form, a_trans = 0, b_trans = 1) writes d(pre) of the layer below directly
+                                  instead of d(post) + a wj_gelu_bwd_bf16 pass over the same rows */
 };
 typedef struct {
     const void* A;

@@ -88,6 +88,8 @@ def test_gemm_bias_gelu2(ops):
     (20000, 1024, 384, "BIAS_GELU2"),   # two outputs, tiles pulled from the per-XCD counters
     (20000, 768, 256, "BIAS_GELU"),
     (16080, 512, 1024, "CONV_GELU"),    # 40 segments of 402 rows, 400 valid
+    (16384, 2304, 256, "BIAS_GELU"),    # 64 panels x 9 items: every XCD owns whole panels (the shapes WJ_PERSIST_WBLOCK re-orders)
+    (8192, 3072, 128, "BF16"),          # 32 panels x 12 items
 ])
 def test_gemm_persistent_schedule(ops, M, N, K, epi):
     """The persistent eight-phase kernel (csrc/gemm_persist.hip, variant 4) through the C ABI: fp32 torch reference at bf16 resolution;
@@ -365,6 +367,18 @@ def test_gemm_gather_forms(ops):
     mask = torch.ones(out.shape[0] * C // (s_ * C), dtype=torch.bool, device=dev())
     mask[sel.long()] = False
     assert float(out.view(-1)[: mask.numel() * s_ * C].view(-1, s_ * C)[mask].abs().max()) == 0.0   # nothing else written
+    # --- the same dgrad with GELU' of the layer below fused into its epilogue: exactly the bits of the plain form followed by
+    #     wj_gelu_bwd_bf16 over the rows it wrote (and nothing else written)
+    pre = rnd(rows_in + 16, C, scale=1.5, dtype=torch.bfloat16, seed=25)
+    out2 = torch.zeros(rows_in + 16, C, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a_ptr, wd, out2.data_ptr(), M=n, N=C, K=U * C, lda=C, ldb=C, ldc=s_ * C, b_trans=1, rowmap=sel,
+             epilogue=ops.EPI_MUL_GELU_GRAD_Z, aux=pre.data_ptr())
+    ref2 = torch.zeros_like(out)
+    ops.gelu_bwd_bf16(out, pre, ref2, out.numel())
+    view = lambda t: t.view(-1)[: (rows_in // s_) * s_ * C].view(-1, s_ * C)
+    assert torch.equal(view(out2)[sel.long(), :C].view(torch.int16), view(ref2)[sel.long(), :C].view(torch.int16))
+    full = out2.view(-1)[: mask.numel() * s_ * C].view(-1, s_ * C)
+    assert float(full[mask].abs().max()) == 0.0 and float(full[:, C:].abs().max()) == 0.0
     # --- wgrad (k gather): dW[o][kk*C + c] = sum_{g in list} dY[g][o] * X[s*g + kk][c]
     dy = rnd(rows_out, C, dtype=torch.bfloat16, seed=23)
     x = rnd(rows_in + 16, C, scale=0.3, dtype=torch.bfloat16, seed=24)

@@ -24,6 +24,7 @@ CLASSES = [   # (label, regex on the kernel name); first match wins
     ("gemm NT (col-form B) BF16", r"gemm3_kernel<false, true, 0,"),
     ("gemm NT MUL_GELU_GRAD", r"gemm3_kernel<false, true, 2,"),
     ("gemm NT ADD_F32", r"gemm3_kernel<false, true, 3,"),
+    ("gemm NT gather dgrad + GELU'", r"gemm3_kernel<false, true, 7,"),
     ("gemm NN one-tile BF16", r"gemm3_kernel<false, false, 0,"),
     ("gemm NN one-tile other", r"gemm3_kernel<false, false,"),
     ("gemm TT wgrad (ungrouped)", r"gemm3_kernel<true, true,"),

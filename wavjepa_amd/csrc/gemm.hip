@@ -671,7 +671,8 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
     static_assert(GATHER == 0 || SCHED == 0, "gather forms use the plain schedule");
     static_assert(SCHED < 2 || (!AT && !BT), "eight-phase schedules: row-form operands");
     static_assert(SCHED != 3 || EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2, "MX fp8 loop: forward epilogues");
-    static_assert(GATHER != 1 || (!AT && EPI == WJ_EPI_BF16), "row gather: row-form A, bf16 output");
+    static_assert(GATHER != 1 || (!AT && (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_MUL_GELU_GRAD_Z)), "row gather: row-form A, bf16 output");
+    static_assert(EPI != WJ_EPI_MUL_GELU_GRAD_Z || GATHER == 1, "gelu'(z) epilogue: built for the sparse conv dgrad");
     static_assert(GATHER != 2 || (AT && BT && BN == 256), "k gather: col-form A and B, 256-wide tiles");
     constexpr int S = C_::STAGES, A_BYTES = C_::A_BYTES, STAGE_BYTES = C_::STAGE_BYTES, LPT = C_::LOADS_PER_TILE, MI = C_::MI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1042,13 +1043,15 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
             }
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             constexpr bool CS = (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_MUL_GELU_GRAD);
-            if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD) {
+            if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD || EPI == WJ_EPI_MUL_GELU_GRAD_Z) {
 #pragma unroll
                 for (int ps = 0; ps < PASSES; ++ps) {
                     const int m = mh + rr + RPP * ps;
 #pragma unroll
                     for (int x = 0; x < 8; ++x) hx[ps][x] = f2bf(0.f);
-                    if (ncol && m < M) hx[ps] = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.aux + (long)m * e.ldc + n);
+                    long arow = m;
+                    if constexpr (GATHER == 1) arow = crow[ps];          // aux lives at C's own (gathered) rows
+                    if (ncol && m < M) hx[ps] = *reinterpret_cast<const bf16x8*>((const bf16_t*)e.aux + arow * e.ldc + n);
                 }
             }
 #pragma unroll
@@ -1121,6 +1124,11 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
 #pragma unroll
                         for (int x = 0; x < 8; ++x) csum[x] += bf2f(o[x]);
                     }
+                } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD_Z) {
+                    bf16x8 o;            // d(pre) = bf16(d(post)) * gelu'(pre): the bits of a bf16 d(post) tensor followed by wj_gelu_bwd_bf16
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) o[x] = f2bf(bf2f(v[x]) * gelu_grad_f(bf2f(hx[ps][x])));
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
                 } else if constexpr (EPI == WJ_EPI_CONV_GELU) {
                     const bool valid = (m % e.seg_rows) < e.seg_valid;
                     bf16x8 pre, post, unused;
@@ -1438,6 +1446,7 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return WJ_ERR_ARG;
     if ((a->epilogue == WJ_EPI_BIAS_GELU2 || a->epilogue == WJ_EPI_CONV_GELU) && !a->C2) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD && !a->aux) return WJ_ERR_ARG;
+    if (a->epilogue == WJ_EPI_MUL_GELU_GRAD_Z && (!a->aux || !a->rowmap || ((uintptr_t)a->aux & 15))) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
     if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1445,6 +1454,8 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
         // gather forms (sparse conv backward), one instantiation each
         if (!a->a_trans && a->b_trans && a->epilogue == WJ_EPI_BF16 && !a->colsum && !a->bias)
             return launch<false, true, WJ_EPI_BF16, 128, 0, 1>(a, s);
+        if (!a->a_trans && a->b_trans && a->epilogue == WJ_EPI_MUL_GELU_GRAD_Z && !a->colsum && !a->bias && a->aux)
+            return launch<false, true, WJ_EPI_MUL_GELU_GRAD_Z, 128, 0, 1>(a, s);
         if (a->a_trans && a->b_trans && a->epilogue == WJ_EPI_ATOMIC_F32) return launch<true, true, WJ_EPI_ATOMIC_F32, 256, 0, 2>(a, s);
         return WJ_ERR_UNSUPPORTED;
     }

@@ -30,6 +30,7 @@
 //     other waves through an LDS word.  Workgroups that start late (a second stream holds their CU) simply pull fewer tiles.  Every
 //     workgroup makes exactly one failing pull, so a launch draws exactly chunk_len values from each counter and the pull that draws
 //     the last one resets it: no memset between launches, no host-side state besides a stream -> counter-slot table.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -74,6 +75,7 @@ struct PArgs {
     int items_n;              // work items per 256-row panel: full tiles (the last one shifted inwards if N % 256 is neither 0 nor 128) ...
     int half_item;            // ... and, if 1, a last HALF-WIDTH item: columns [N - 128, N), the MFMA clusters of phases 1 / 2 skipped
     int wpx;                  // resident workgroups per XCD (grid = 8 wpx; 32 = every CU)
+    int wb_panels, wb_cols;   // W blocking (experiment, WJ_PERSIST_WBLOCK): an XCD walks its panels in blocks of wb_panels x wb_cols items (0: panel by panel)
     int nostore;              // diagnostic (WJ_PERSIST_DIAG_NOSTORE=1): the epilogue computes but does not store -- what the store path costs
     int stagger;              // start-up de-phasing: workgroup j of an XCD starts j * stagger / wpx ticks of the 100 MHz clock late
     int seg_rows, seg_valid;
@@ -564,8 +566,22 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     const long half_adj = (long)((wave >> 1) * 32) * a.ldb_b;
     auto tile_coords = [&](int q, int& m0, int& n0, bool& half, int& skip) {
         const int L = cstart + q;
-        const int tm = L / a.items_n;
-        const int j = L - tm * a.items_n;
+        int tm = L / a.items_n;
+        int j = L - tm * a.items_n;
+        if (a.wb_panels > 0) {
+            // blocked walk (the host only asks for it when this XCD's run of items is whole panels): blocks of wb_panels panels, inside a
+            // block column groups of wb_cols items, inside a group panel by panel -- the ~32 items an XCD has in flight are then
+            // wb_panels x wb_cols instead of 2.7 panels x every column: W is fetched per column group, A per group of a block
+            const int pfirst = cstart / a.items_n, npan = clen / a.items_n;
+            const int per = a.wb_panels * a.items_n;
+            const int lb = q / per, rem = q - lb * per;
+            const int psz = min(a.wb_panels, npan - lb * a.wb_panels);
+            const int grp = psz * a.wb_cols;
+            const int cb = rem / grp, r2 = rem - cb * grp;
+            const int pp = r2 / a.wb_cols;
+            tm = pfirst + lb * a.wb_panels + pp;
+            j = cb * a.wb_cols + (r2 - pp * a.wb_cols);
+        }
         m0 = min(tm * 256, a.M - 256);                 // edge tiles are shifted inwards
         skip = tm * 256 - m0;                          // rows of a shifted tile that its neighbour owns
         half = a.half_item && j == a.items_n - 1;
@@ -776,6 +792,19 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
     p.ntiles = ((a->M + 255) / 256) * p.items_n;
     p.wpx = persist_wpx();
     p.stagger = persist_stagger(a);
+    {
+        // WJ_PERSIST_WBLOCK="<panels>x<cols>" (e.g. 8x4): blocked tile order for shapes with N >= 2304 whose per-XCD run of items is whole
+        // panels and whose item count per panel is a multiple of <cols>; unset / anything else: panel by panel
+        static int wbp = -1, wbc = 0;
+        if (wbp < 0) {
+            wbp = 0;
+            const char* v = getenv("WJ_PERSIST_WBLOCK");
+            if (v) { int x = 0, y = 0; if (sscanf(v, "%dx%d", &x, &y) == 2 && x > 0 && y > 0) { wbp = x; wbc = y; } }
+        }
+        p.wb_panels = 0; p.wb_cols = 0;
+        const int panels = (a->M + 255) / 256;
+        if (wbp > 0 && a->N >= 2304 && !p.half_item && panels % 8 == 0 && p.items_n % wbc == 0) { p.wb_panels = wbp; p.wb_cols = wbc; }
+    }
     {
         static int ns = -1;
         if (ns < 0) { const char* v = getenv("WJ_PERSIST_DIAG_NOSTORE"); ns = v ? atoi(v) : 0; }

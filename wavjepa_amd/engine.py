@@ -315,6 +315,8 @@ class JepaEngine:
         # conv backward over the active rows only (needs a ragged step and k >= stride in every GEMM conv layer)
         self.sparse_conv = _os.environ.get("WJ_SPARSE_CONV", "1") != "0" and all(k >= st for _, k, st in cfg.conv_spec[1:])
         self._conv_grads_dirty = False
+        # GELU' of conv layers 1..n-2 in the epilogue of the sparse dgrad above them (WJ_FUSE_CONV_GELU_BWD=0: separate passes)
+        self.fuse_conv_gelu_bwd = _os.environ.get("WJ_FUSE_CONV_GELU_BWD", "1") != "0"
         # last predictor layer: after its attention only the target rows go on (WJ_TRIM_TAIL=0: every visible row)
         self.trim_tail = _os.environ.get("WJ_TRIM_TAIL", "1") != "0"
         self.tail = None
@@ -1226,8 +1228,10 @@ class JepaEngine:
                     # the rows written this step (they are cleared again below), so the dgrad taps may read neighbours freely.
                     # The lists hold rows of the WHOLE buffer; a group takes its contiguous slice of them.
                     act, n_act, ext, n_ext = act_rows[l][gi]
-                    ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], 0, rows=act, n_rows=n_act, row_elems=C,
-                                      clear_dpost=l < nl - 1)
+                    if not (self.fuse_conv_gelu_bwd and l < nl - 1):
+                        # (layers below the top one: d(pre) was written by the dgrad of the layer above, GELU' fused in its epilogue)
+                        ops.gelu_bwd_bf16(self.dpost_ptr[l], self.pre_ptr[l], self.dpre_ptr[l], 0, rows=act, n_rows=n_act, row_elems=C,
+                                          clear_dpost=l < nl - 1)
                     if n_act > 0:
                         ops.gemm(self.dpre_ptr[l], self.post_ptr[l - 1], dwp, M=C, N=k * C, K=n_act, lda=C, ldb=s * C, ldc=k * C, a_trans=1,
                                  b_trans=1, epilogue=ops.EPI_ATOMIC_F32, split_k=ops.pick_split_k(C, k * C, n_act), rowmap=act)
@@ -1241,7 +1245,13 @@ class JepaEngine:
                     if U == 0:
                         continue
                     if sparse:
-                        if n_ext > 0:
+                        if n_ext > 0 and self.fuse_conv_gelu_bwd and l - 1 >= 1:
+                            # the rows this GEMM writes (s g + rho, g in ext) are exactly act[l - 1]: d(pre[l - 1]) = bf16(d(post)) * gelu'(pre)
+                            # straight from its epilogue -- the bits a bf16 d(post) tensor + wj_gelu_bwd_bf16 over act[l - 1] would give
+                            ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"{si}:wd{l}_{rho}"], self.dpre_ptr[l - 1] + rho * C * 2,
+                                     M=n_ext, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1, rowmap=ext,
+                                     epilogue=ops.EPI_MUL_GELU_GRAD_Z, aux=self.pre_ptr[l - 1] + rho * C * 2)
+                        elif n_ext > 0:
                             ops.gemm(self.dpre_ptr[l] - (U - 1) * C * 2, self._conv_w[f"{si}:wd{l}_{rho}"], self.dpost_ptr[l - 1] + rho * C * 2,
                                      M=n_ext, N=C, K=U * C, lda=C, ldb=C, ldc=s * C, b_trans=1, rowmap=ext)
                     else:
