@@ -100,10 +100,24 @@ __global__ __launch_bounds__(256) void conv0_fold_kernel(const float* __restrict
 //   conv : P = audio patches (rows = 16 time steps), Q = weights (rows = 16 channels)  -> lane: channel i, times 4g+r
 //   YX   : Q' = that result for two 16-step blocks (row = channel i, logical k = 8g+j <-> time kappa(g,j) = j<4 ? 4g+j : 16+4g+j-4),
 //          P' = audio patches with rows = taps and the same kappa order                  -> lane: channel i, taps 4g+r
-constexpr int TCS = 1024;  // time steps per workgroup (few, long workgroups: 7 partial records per clip at 6430 steps)
+// Time steps per workgroup of the statistics pass.  Round 4: a constant 1024 -- at 256 clips x 6430 steps 1792 workgroups for the 768 the
+// chip holds (160 VGPRs: three 4-wave workgroups per CU), i.e. 2.33 rounds that cost three.  Now the chunk count is chosen so that the
+// launch is about ONE round (256 clips: 3 chunks of 2144 steps = 768 workgroups; fewer clips: more, shorter chunks), a multiple of 32.
+constexpr int STATS_SLOTS = 768;
+inline int stats_tcs(int N, int L_out, int C_in) {
+    static int forced = -1;
+    if (forced < 0) { const char* v = getenv("WJ_CONV0_STATS_TCS"); forced = v ? atoi(v) : 0; }     // A/B runs (1024: the round-4 chunks)
+    if (forced >= 32) return forced / 32 * 32;
+    int chunks = (STATS_SLOTS + N / 2) / (N > 0 ? N : 1);
+    const int most = (L_out + 255) / 256;
+    chunks = chunks < 1 ? 1 : (chunks > most ? most : chunks);
+    const int tcs = ((L_out + chunks - 1) / chunks + 31) / 32 * 32;
+    const int cap = 2176 / (C_in > 0 ? C_in : 1) / 32 * 32;           // the chunk's audio samples live in LDS (bf16, C_in x ~5 tcs): <= ~44 KB
+    return tcs > cap ? (cap < 32 ? 32 : cap) : tcs;
+}
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
-                                                               float* __restrict__ part, int want_yx, Geo g, int span) {
+                                                               float* __restrict__ part, int want_yx, Geo g, int span, int TCS) {
     extern __shared__ __attribute__((aligned(16))) bf16_t xa[];   // [C_in][span] samples of this chunk (0 past the clip)
     constexpr int QT = (TAPS + 15) / 16;
     const int n = blockIdx.y, t0 = blockIdx.x * TCS;
@@ -295,8 +309,11 @@ __global__ __launch_bounds__(NTH) void conv0_apply_kernel(const bf16_t* __restri
 //   GroupNorm is applied in its folded form z = y * (rstd gamma) + (beta - mean rstd gamma) (two constants per channel instead of four:
 //   a lane serves 16 channels).
 constexpr int TCA = 512;  // output time steps per workgroup of the MFMA form
-template <int TAPS>
-__global__ __launch_bounds__(512) void conv0_apply_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
+// MINB: workgroups per CU the register allocation must allow (the second __launch_bounds__ argument counts WAVES PER SIMD: 4 for two
+// 8-wave workgroups).  At 134 VGPRs (MINB = 1) a CU holds 12 waves = ONE 8-wave workgroup, two
+// waves per SIMD under a loop of dependent transcendentals; MINB = 2 caps the kernel at 128 VGPRs: two workgroups, four waves per SIMD.
+template <int TAPS, int MINB = 1>
+__global__ __launch_bounds__(512, MINB == 2 ? 4 : 1) void conv0_apply_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ sums, bf16_t* __restrict__ act,
                                                                float* __restrict__ mean_o, float* __restrict__ rstd_o, Geo g, int span,
@@ -528,21 +545,28 @@ void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStrea
     const size_t lds = (size_t)a->C_in * span_max * sizeof(float);
     dim3 grid2((a->P + TC - 1) / TC, a->N), block(NTH);
     const int want_yx = a->yx != nullptr;
+    const int TCS = stats_tcs(a->N, a->L_out, a->C_in);
     const int chunks = (a->L_out + TCS - 1) / TCS;
     const long rec = fwd_record<TAPS>(a->C, want_yx);
     float* sums = a->workspace;                       // [N][C][2] folded statistics
     float* part = a->workspace + 2L * a->N * a->C;    // [N][chunks][rec] partial records
     const int span = (TCS - 1) * a->stride + a->k;
     hipLaunchKernelGGL(conv0_stats_mfma_kernel<TAPS>, dim3(chunks, a->N), dim3(256), (size_t)a->C_in * span * sizeof(bf16_t), s,
-                       (const bf16_t*)a->audio, (const bf16_t*)a->w, part, want_yx, g, span);
+                       (const bf16_t*)a->audio, (const bf16_t*)a->w, part, want_yx, g, span, TCS);
     hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
                        sums, 2L * a->C, a->yx, (long)a->C * TAPS, a->x1, (const int32_t*)nullptr, 1);
     static const int use_mfma = [] { const char* e = getenv("WJ_CONV0_APPLY_MFMA"); return e ? atoi(e) : 1; }();   // 0: the VALU form (A/B runs)
     if (use_mfma && a->C % 64 == 0 && TAPS <= 32) {
         const int span_a = (TCA - 1) * a->stride + a->k;
-        hipLaunchKernelGGL(conv0_apply_mfma_kernel<TAPS>, dim3((a->P + TCA - 1) / TCA, a->N), dim3(512), (size_t)a->C_in * span_a * sizeof(bf16_t),
-                           s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean,
-                           a->rstd, g, span_a, a->eps);
+        static const int occ = [] { const char* e = getenv("WJ_CONV0_APPLY_OCC"); return e ? atoi(e) : 1; }();      // 2: 128 VGPRs, two workgroups per CU -- measured 836 against 851 us alone and nothing on top of the re-chunked statistics pass (profiles/r05_conv0_variants.log): the pass is VALU-throughput-bound, not latency-bound
+        if (occ >= 2)
+            hipLaunchKernelGGL((conv0_apply_mfma_kernel<TAPS, 2>), dim3((a->P + TCA - 1) / TCA, a->N), dim3(512), (size_t)a->C_in * span_a * sizeof(bf16_t),
+                               s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean,
+                               a->rstd, g, span_a, a->eps);
+        else
+            hipLaunchKernelGGL((conv0_apply_mfma_kernel<TAPS, 1>), dim3((a->P + TCA - 1) / TCA, a->N), dim3(512), (size_t)a->C_in * span_a * sizeof(bf16_t),
+                               s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean,
+                               a->rstd, g, span_a, a->eps);
         return;
     }
     hipLaunchKernelGGL(conv0_apply_kernel<TAPS>, grid2, block, lds, s, (const bf16_t*)a->audio, (const bf16_t*)a->w,
@@ -573,6 +597,7 @@ void launch_bwd(const wj_conv0_bwd_args* a, const Geo& g, hipStream_t s) {
 
 // scratch sizes (wj_workspace_bytes): folded statistics + one partial record per (clip, chunk)
 int64_t wj_conv0_fwd_ws_bytes(const wj_conv0_fwd_args* a) {
+    const int TCS = stats_tcs(a->N, a->L_out, a->C_in);
     const int taps = a->C_in * a->k, chunks = (a->L_out + TCS - 1) / TCS;
     const long rec = 2L * a->C + (long)a->C * taps + taps;      // sized for the training form (yx / x1 requested)
     return (2L * a->N * a->C + (long)a->N * chunks * rec) * 4;

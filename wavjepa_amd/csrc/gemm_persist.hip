@@ -75,7 +75,7 @@ struct PArgs {
     int items_n;              // work items per 256-row panel: full tiles (the last one shifted inwards if N % 256 is neither 0 nor 128) ...
     int half_item;            // ... and, if 1, a last HALF-WIDTH item: columns [N - 128, N), the MFMA clusters of phases 1 / 2 skipped
     int wpx;                  // resident workgroups per XCD (grid = 8 wpx; 32 = every CU)
-    int wb_panels, wb_cols;   // W blocking (experiment, WJ_PERSIST_WBLOCK): an XCD walks its panels in blocks of wb_panels x wb_cols items (0: panel by panel)
+    int wb_panels, wb_cols;   // W blocking (WJ_PERSIST_WBLOCK): an XCD walks its panels in blocks of wb_panels x wb_cols items (0: panel by panel)
     int nostore;              // diagnostic (WJ_PERSIST_DIAG_NOSTORE=1): the epilogue computes but does not store -- what the store path costs
     int stagger;              // start-up de-phasing: workgroup j of an XCD starts j * stagger / wpx ticks of the 100 MHz clock late
     int seg_rows, seg_valid;
@@ -793,13 +793,15 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
     p.wpx = persist_wpx();
     p.stagger = persist_stagger(a);
     {
-        // WJ_PERSIST_WBLOCK="<panels>x<cols>" (e.g. 8x4): blocked tile order for shapes with N >= 2304 whose per-XCD run of items is whole
-        // panels and whose item count per panel is a multiple of <cols>; unset / anything else: panel by panel
+        // Blocked tile order for shapes with N >= 2304 whose per-XCD run of items is whole panels and whose item count per panel is a
+        // multiple of <cols>: default 8 panels x 4 columns (the teacher's / student's linear1 + GELU, N = 3072: 278 -> 269 us per teacher
+        // launch, same-box A/B profiles/r05_ab_wblock.txt; N = 2304 has 9 items per panel and keeps the panel-by-panel walk, where 8x3
+        // measured nothing).  WJ_PERSIST_WBLOCK="<panels>x<cols>" overrides, "0" switches it off.
         static int wbp = -1, wbc = 0;
         if (wbp < 0) {
-            wbp = 0;
+            wbp = 8; wbc = 4;
             const char* v = getenv("WJ_PERSIST_WBLOCK");
-            if (v) { int x = 0, y = 0; if (sscanf(v, "%dx%d", &x, &y) == 2 && x > 0 && y > 0) { wbp = x; wbc = y; } }
+            if (v) { int x = 0, y = 0; wbp = 0; if (sscanf(v, "%dx%d", &x, &y) == 2 && x > 0 && y > 0) { wbp = x; wbc = y; } }
         }
         p.wb_panels = 0; p.wb_cols = 0;
         const int panels = (a->M + 255) / 256;
