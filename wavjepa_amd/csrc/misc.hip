@@ -178,8 +178,13 @@ __global__ __launch_bounds__(256) void scatter_fill_rows_kernel(wj_scatter_fill_
 // gradient of a workgroup goes to a row of `partials` (no atomics; folded by wj_colsum_f32_group) when the caller gives one.
 constexpr int SFB_WROWS = 4;                 // rows per wave
 constexpr int SFB_ROWS = 4 * SFB_WROWS;      // rows per workgroup
+// JMAX: 256-float column blocks a lane may own (2: D <= 512 -- half the registers, so that two waves per SIMD fit beside a weight-gradient
+// workgroup of the other stream, which is what this kernel runs against on the main stream's critical path; 4: D <= 1024)
+template <int JMAX>
 __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_bwd_args a) {
-    __shared__ float macc[4][1024];
+    // [4 waves][D] floats, sized at launch: a fixed [4][1024] (16 KB) left room for two of these workgroups beside a weight-gradient
+    // workgroup of the other stream (128 KB of a CU's 160) and the kernel, on the main stream's critical path, ran 405 us instead of 90
+    extern __shared__ float macc_dyn[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = a.D, M = a.B * a.T, G = a.G;
     const int m0 = blockIdx.x * SFB_ROWS + wave * SFB_WROWS;
@@ -197,27 +202,42 @@ __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_b
             }
         }
     }
-    f32x4 mt[4];
+    f32x4 mt[JMAX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) mt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JMAX; ++j) mt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < SFB_WROWS; ++r) {
         if (m0 + r >= M) break;
         const int dst = __builtin_amdgcn_readlane(idx, r * (G + 1) + G);
-        f32x4 s[4];
+        f32x4 s[JMAX];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < G; ++g) {
-            const int row = __builtin_amdgcn_readlane(idx, r * (G + 1) + g);
-            if (row < 0) continue;
+        for (int j = 0; j < JMAX; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // four groups at a time, branch-free: every load of the batch is issued before the first add (with a `continue` on invisible
+        // rows the loads of successive groups were separated by control flow -- one memory round trip per group and row)
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            f32x4 v[4][JMAX];
+            bool ok[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = lane * 4 + 256 * j;
-                if (c < D) s[j] += *reinterpret_cast<const f32x4*>(a.d_in + (long)row * D + c);
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u;
+                const int row = g < G ? __builtin_amdgcn_readlane(idx, r * (G + 1) + (g < G ? g : 0)) : -1;
+                ok[u] = row >= 0;
+                const float* src = a.d_in + (long)(ok[u] ? row : 0) * D;
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) {
+                    const int c = lane * 4 + 256 * j;
+                    v[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (c < D) v[u][j] = *reinterpret_cast<const f32x4*>(src + c);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j)
+                    if (ok[u]) s[j] += v[u][j];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < JMAX; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
                 if (dst >= 0) {
@@ -233,13 +253,13 @@ __global__ __launch_bounds__(256) void scatter_fill_bwd_kernel(wj_scatter_fill_b
     }
     if (!a.d_mask_token) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JMAX; ++j) {
         const int c = lane * 4 + 256 * j;
-        if (c < D) *reinterpret_cast<f32x4*>(&macc[wave][c]) = mt[j];
+        if (c < D) *reinterpret_cast<f32x4*>(&macc_dyn[wave * D + c]) = mt[j];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-        const float v = (macc[0][c] + macc[1][c]) + (macc[2][c] + macc[3][c]);
+        const float v = (macc_dyn[c] + macc_dyn[D + c]) + (macc_dyn[2 * D + c] + macc_dyn[3 * D + c]);
         if (a.partials) a.partials[(long)blockIdx.x * D + c] = v;
         else atomicAdd(a.d_mask_token + c, v);
     }
@@ -760,7 +780,8 @@ extern "C" int wj_mask_scatter_fill_pos_bwd(const wj_scatter_fill_bwd_args* a, v
         a->G <= 0 || a->G > 15)              // (a wave's 4 rows x (G + 1) indices are fetched by one load per lane)
         return WJ_ERR_ARG;
     const int grid = (a->B * a->T + SFB_ROWS - 1) / SFB_ROWS;
-    hipLaunchKernelGGL(scatter_fill_bwd_kernel, dim3(grid), dim3(256), 0, STREAM, *a);
+    if (a->D <= 512) hipLaunchKernelGGL(scatter_fill_bwd_kernel<2>, dim3(grid), dim3(256), (size_t)4 * a->D * sizeof(float), STREAM, *a);
+    else hipLaunchKernelGGL(scatter_fill_bwd_kernel<4>, dim3(grid), dim3(256), (size_t)4 * a->D * sizeof(float), STREAM, *a);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }
