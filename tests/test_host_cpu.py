@@ -225,7 +225,10 @@ def test_workspace_query():
     assert ops.workspace_bytes("wj_layernorm_bwd", D=768) == 1536 * 3 * 768 * 4
     assert ops.workspace_bytes("wj_attn_bwd", B=1024, H=12, hd=32) == 1024 * 3 * 384 * 4
     # conv0: folded sums + one partial record per (clip, chunk) -- stored and folded in order, no float atomics
-    assert ops.workspace_bytes("wj_conv0_gn_gelu_fwd", N=256, C=512, C_in=1, k=10, L_out=6430) == (2 * 256 * 512 + 256 * 7 * (512 * 12 + 10)) * 4
+    # (round 5: the chunk count follows the clip count -- about one round of the chip's 768 resident workgroups: 3 chunks at 256 clips,
+    # 12 at 64 clips; round 4: always ceil(L_out / 1024) = 7)
+    assert ops.workspace_bytes("wj_conv0_gn_gelu_fwd", N=256, C=512, C_in=1, k=10, L_out=6430) == (2 * 256 * 512 + 256 * 3 * (512 * 12 + 10)) * 4
+    assert ops.workspace_bytes("wj_conv0_gn_gelu_fwd", N=64, C=512, C_in=1, k=10, L_out=6430) == (2 * 64 * 512 + 64 * 12 * (512 * 12 + 10)) * 4
     assert ops.workspace_bytes("wj_conv0_gn_gelu_bwd", N=256, C=512, C_in=1, k=10, L_out=6430) == 256 * (1 + 26) * 512 * 12 * 4
     assert ops.workspace_bytes("wj_conv0_gn_gelu_bwd", N=256, C=512, C_in=1, k=10, L_out=6430, max_rows=1300) == 256 * (1 + 6) * 512 * 12 * 4
     assert ops.workspace_bytes("wj_masked_mse", B=256, G=4, T=200) == (2 + 204800) * 4
