@@ -39,11 +39,10 @@ constexpr long PAIR_TILE_BYTES = 2L * 4 * 32 * 64 * 16;   // K-split pairs: scra
 
 // BMT: tile rows.  256 everywhere except the 384 x 128 tile of the predictor's grouped weight gradients (every dimension of those
 // products is a multiple of 384: with 256-row tiles 14 % of their MFMA work fell on rows past the edge).
-#ifndef WJ_WGRAD384_STAGES
-#define WJ_WGRAD384_STAGES 4
-#endif
 template <int BN, int BMT = 256> struct Cfg {
-    static constexpr int STAGES = BN == 256 ? 4 : (BMT == 384 ? WJ_WGRAD384_STAGES : 3);
+    // (384 x 128: a 3-stage ring -- 96 instead of 128 KB of LDS -- measured the same, 311.5 / 313.9 us per launch and 45.88 / 45.90 ms per
+    // two-stream step, interleaved on one box)
+    static constexpr int STAGES = (BN == 256 || BMT == 384) ? 4 : 3;
     static constexpr int A_BYTES = BMT * BK * 2;                       // 16384 (24576 for 384 rows)
     static constexpr int B_BYTES = BN * BK * 2;                        // 16384 / 8192
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;              // 32768 / 24576
