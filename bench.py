@@ -70,7 +70,7 @@ def build_model(device, seed: int, seconds: float = 2.01, nat: bool = False):
 
 
 def gemm_kernel_name(f) -> str:
-    epi = {0: "BF16", 1: "BIAS_GELU2", 2: "MUL_GELU_GRAD", 3: "ADD_F32", 4: "ATOMIC_F32", 5: "CONV_GELU", 6: "BIAS_GELU", 7: "MUL_GELU_GRAD_Z"}[f["epilogue"]]
+    epi = {0: "BF16", 1: "BIAS_GELU2", 2: "MUL_GELU_GRAD", 3: "ADD_F32", 4: "ATOMIC_F32", 5: "CONV_GELU", 6: "BIAS_GELU", 7: "MUL_GELU_GRAD_Z", 8: "BF16_ADD_POS"}[f["epilogue"]]
     return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
 
 
@@ -94,7 +94,7 @@ def pmc_traffic_for(name: str):
     m = __import__("re").match(r"gemm_kernel<([NT])([NT]),(\w+)>", name)
     if not m or not os.path.exists(path):
         return None
-    epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5, "MUL_GELU_GRAD_Z": 7}[m.group(3)]
+    epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5, "MUL_GELU_GRAD_Z": 7, "BF16_ADD_POS": 8}[m.group(3)]
     prefix = f"gemm3_kernel<{'true' if m.group(1) == 'T' else 'false'}, {'true' if m.group(2) == 'T' else 'false'}, {epi},"
     pn = 6 if m.group(3) == "BIAS_GELU" else epi                                      # the persistent variant of the forward shapes
     persist = (f"gemm_persist_kernel<{pn}>", f"gemm_persist_kernel<{pn},")
@@ -111,7 +111,7 @@ def gemm_class_patterns(name: str):
     m = re.match(r"gemm_kernel<([NT])([NT]),(\w+)>", name)
     if not m:
         return None
-    epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5, "MUL_GELU_GRAD_Z": 7}[m.group(3)]
+    epi = {"BF16": 0, "BIAS_GELU2": 1, "BIAS_GELU": 1, "MUL_GELU_GRAD": 2, "ADD_F32": 3, "ATOMIC_F32": 4, "CONV_GELU": 5, "MUL_GELU_GRAD_Z": 7, "BF16_ADD_POS": 8}[m.group(3)]
     pn = 6 if m.group(3) == "BIAS_GELU" else epi
     pats = [f"gemm3_kernel<{'true' if m.group(1) == 'T' else 'false'}, {'true' if m.group(2) == 'T' else 'false'}, {epi},"]
     if m.group(1) == "N" and m.group(2) == "N":
@@ -172,7 +172,7 @@ def profile_one_step(runner, source, step_idx: int):
             name, flops = gemm_kernel_name(f), 2.0 * f["M"] * f["N"] * f["K"]
             ep = f["epilogue"]
             outb = 4 if ep in (3, 4) else 2
-            nbytes = 2.0 * f["K"] * (f["M"] + f["N"]) + f["M"] * f["N"] * (outb * (2 if ep in (1, 5) else 1) + (outb if ep in (2, 3, 7) else 0))
+            nbytes = 2.0 * f["K"] * (f["M"] + f["N"]) + f["M"] * f["N"] * (outb * (2 if ep in (1, 5) else 1) + (outb if ep in (2, 3, 7) else 0) + (4 if ep == 8 else 0))
             key = f"{name} M={f['M']} N={f['N']} K={f['K']}" + (" gather" if f.get("rowmap") else "")
             sh = shapes.setdefault(key, dict(ms=0.0, flops=0.0, launches=0))
             sh["ms"] += ms; sh["flops"] += flops; sh["launches"] += 1

@@ -45,6 +45,9 @@ enum {
     WJ_EPI_ATOMIC_F32 = 4,    /* C(f32)  += alpha * acc   (atomic; split_k >= 1)   (wgrad into the grad buffer) */
     WJ_EPI_CONV_GELU = 5,     /* C(bf16)  = pre = bf16(acc); C2(bf16) = gelu(pre); rows (m % seg_rows) >= seg_valid -> 0 */
     WJ_EPI_BIAS_GELU = 6,     /* C(bf16)  = gelu(bf16(acc + bias))      (linear1 + nn.GELU where no backward follows: teacher) */
+    WJ_EPI_BF16_ADD_POS = 8,  /* y = float(bf16(acc + bias)) + aux[(m % seg_rows)][n] (aux = f32 position table [seg_rows][N]);  C2(f32) = y,
+                                  C(bf16) = bf16(y): the post-extraction mapper with the position add of jepa.py:394-396 in its epilogue
+                                  (SURVEY K8 + K9) instead of a separate pass over the 51 200 x 768 token tensor.  C2 may be NULL. */
     WJ_EPI_MUL_GELU_GRAD_Z = 7 /* C(bf16) = bf16(acc) * gelu'(aux(bf16)), aux = the PRE-activation z at C's own rows / stride (evaluated here):
                                   the sparse conv dgrad (rowmap form, a_trans = 0, b_trans = 1) writes d(pre) of the layer below directly
                                   instead of d(post) + a wj_gelu_bwd_bf16 pass over the same rows */

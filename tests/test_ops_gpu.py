@@ -1231,3 +1231,36 @@ def test_gemm_persistent_counter_slots_are_recycled(ops):
             assert torch.equal(C.view(torch.int16), ref.view(torch.int16))
     finally:
         ops.gemm_set_variant(prev)
+
+
+@pytest.mark.parametrize("M,N,K,T", [(5000, 768, 512, 200), (2100, 256, 128, 99), (777, 512, 64, 50)])
+def test_gemm_add_pos_epilogue_equals_gemm_then_add_pos(ops, M, N, K, T):
+    """WJ_EPI_BF16_ADD_POS (the post-extraction mapper with the position add of jepa.py:394-396 in its epilogue, SURVEY K8 + K9) gives
+    exactly the bits of the two-launch form: bf16 mapper output, then wj_add_pos."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=41)
+    W = rnd(N, K, scale=0.06, dtype=torch.bfloat16, seed=42)
+    bias = rnd(N, seed=43)
+    pos = rnd(T, N, seed=44)
+    mid = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(A, W, mid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+    y32 = torch.empty(M, N, device=dev())
+    y16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.add_pos(mid, pos, M=M, T=T, D=N, y_f32=y32, y_bf16=y16)
+    f32 = torch.full((M, N), float("nan"), device=dev())
+    f16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.gemm(A, W, f16, C2=f32, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, epilogue=ops.EPI_BF16_ADD_POS, aux=pos, seg_rows=T)
+    torch.cuda.synchronize()
+    # (the two-launch form may run the persistent schedule, whose bias-first accumulation differs in the last place on <= 0.05 % of the
+    # bf16 mapper outputs: compared against the one-tile schedule the fused epilogue shares)
+    prev = ops.gemm_set_variant(3)
+    try:
+        ops.gemm(A, W, mid, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+    finally:
+        ops.gemm_set_variant(prev)
+    ops.add_pos(mid, pos, M=M, T=T, D=N, y_f32=y32, y_bf16=y16)
+    torch.cuda.synchronize()
+    assert torch.equal(f32, y32) and torch.equal(f16.view(torch.int16), y16.view(torch.int16))
+    ref = (A.float() @ W.float().t() + bias).to(torch.bfloat16).float() + pos.repeat((M + T - 1) // T, 1)[:M]
+    assert relerr(f32, ref) < 4e-3
+    with pytest.raises(Exception):
+        ops.gemm(A, W, f16, C2=f32, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BF16_ADD_POS)      # no position table

@@ -949,7 +949,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) {
+        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_BF16_ADD_POS) {
             const int n = n0 + wn * 64 + ni * 16 + 4 * g;
             if (e.bias && n < N) bv[ni] = *reinterpret_cast<const f32x4*>(e.bias + n);
         }
@@ -978,7 +978,7 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
                     if constexpr (F32_TILE) {
                         *reinterpret_cast<f32x4*>(smem + m * CP + n * 4) = v;
                     } else {
-                        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2) v += bv[ni];
+                        if constexpr (EPI == WJ_EPI_BF16 || EPI == WJ_EPI_BIAS_GELU2 || EPI == WJ_EPI_BF16_ADD_POS) v += bv[ni];
                         bf16x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -1126,6 +1126,24 @@ __device__ __forceinline__ void gemm3_body(const bf16_t* __restrict__ A, const b
 #pragma unroll
                         for (int x = 0; x < 8; ++x) csum[x] += bf2f(o[x]);
                     }
+                } else if constexpr (EPI == WJ_EPI_BF16_ADD_POS) {
+                    // y = float(bf16(acc + bias)) + pos[m % T][n]: what wj_add_pos makes of the mapper's bf16 output, without the round trip
+                    const float* pr = reinterpret_cast<const float*>(e.aux) + (long)(m % e.seg_rows) * N + n;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(pr), p1 = *reinterpret_cast<const f32x4*>(pr + 4);
+                    f32x4 y0, y1;
+                    bf16x8 o;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        y0[x] = bf2f(v[x]) + p0[x];
+                        y1[x] = bf2f(v[4 + x]) + p1[x];
+                        o[x] = f2bf(y0[x]);
+                        o[4 + x] = f2bf(y1[x]);
+                    }
+                    if (e.C2) {
+                        *reinterpret_cast<f32x4*>((float*)e.C2 + off) = y0;
+                        *reinterpret_cast<f32x4*>((float*)e.C2 + off + 4) = y1;
+                    }
+                    *reinterpret_cast<bf16x8*>((bf16_t*)e.C + off) = o;
                 } else if constexpr (EPI == WJ_EPI_MUL_GELU_GRAD_Z) {
                     bf16x8 o;            // d(pre) = bf16(d(post)) * gelu'(pre): the bits of a bf16 d(post) tensor followed by wj_gelu_bwd_bf16
 #pragma unroll
@@ -1324,6 +1342,9 @@ int dispatch_epi(const wj_gemm_args* a, hipStream_t s) {
         case WJ_EPI_ADD_F32: return launch_bn<AT, BT, WJ_EPI_ADD_F32>(a, s);
         case WJ_EPI_ATOMIC_F32: return launch_bn<AT, BT, WJ_EPI_ATOMIC_F32>(a, s);
         case WJ_EPI_CONV_GELU: return launch_bn<AT, BT, WJ_EPI_CONV_GELU>(a, s);
+        case WJ_EPI_BF16_ADD_POS:
+            if constexpr (!AT && !BT) return launch_bn<AT, BT, WJ_EPI_BF16_ADD_POS>(a, s);
+            else return WJ_ERR_UNSUPPORTED;
         default: return WJ_ERR_ARG;
     }
 }
@@ -1448,6 +1469,7 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return WJ_ERR_ARG;
     if ((a->epilogue == WJ_EPI_BIAS_GELU2 || a->epilogue == WJ_EPI_CONV_GELU) && !a->C2) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD && !a->aux) return WJ_ERR_ARG;
+    if (a->epilogue == WJ_EPI_BF16_ADD_POS && (!a->aux || a->seg_rows <= 0 || ((uintptr_t)a->aux & 15) || ((uintptr_t)a->C2 & 15) || a->colsum)) return WJ_ERR_ARG;
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD_Z && (!a->aux || !a->rowmap || ((uintptr_t)a->aux & 15))) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
     if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;

@@ -338,6 +338,7 @@ class JepaEngine:
         self.pair_ws = None
         self._conv_w_fresh = False
         self.defer_folds = _os.environ.get("WJ_DEFER_FOLDS", "1") != "0"
+        self.fuse_add_pos = _os.environ.get("WJ_FUSE_ADD_POS", "1") != "0"     # 0: mapper GEMM + wj_add_pos as two launches
         self._folds = []
         self._bind_params()
         self._bind_wt()
@@ -941,6 +942,11 @@ class JepaEngine:
         ops.layernorm_fwd(self.post_ptr[-1], f.ptr32("feature_norms.weight"), f.ptr32("feature_norms.bias"), M=M, D=C,
                           eps=c.norm_eps, y_bf16=self.fn_b, mean=self.fn_mean, rstd=self.fn_rstd, x_is_bf16=True,
                           in_seg=self.P[-1], in_valid=self.Tc, in_chan=S if S > 1 else 0)
+        if self.has_mapper and self.fuse_add_pos and c.d_enc % 256 == 0 and C % 128 == 0:
+            # mapper + positions in one launch (SURVEY K8 + K9): the position add rides in the GEMM's epilogue
+            ops.gemm(self.fn_b, f.ptr16("post_extraction_mapper.weight"), self.lf_b, C2=self.lf, M=M, N=c.d_enc, K=C, lda=C, ldb=C,
+                     ldc=c.d_enc, bias=f.ptr32("post_extraction_mapper.bias"), epilogue=ops.EPI_BF16_ADD_POS, aux=self.pos_enc, seg_rows=T)
+            return
         if self.has_mapper:
             ops.gemm(self.fn_b, f.ptr16("post_extraction_mapper.weight"), self.map_b, M=M, N=c.d_enc, K=C, lda=C, ldb=C,
                      ldc=c.d_enc, bias=f.ptr32("post_extraction_mapper.bias"))

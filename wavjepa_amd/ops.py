@@ -23,6 +23,7 @@ EPI_ATOMIC_F32 = ENUMS["WJ_EPI_ATOMIC_F32"]
 EPI_CONV_GELU = ENUMS["WJ_EPI_CONV_GELU"]
 EPI_BIAS_GELU = ENUMS["WJ_EPI_BIAS_GELU"]
 EPI_MUL_GELU_GRAD_Z = ENUMS["WJ_EPI_MUL_GELU_GRAD_Z"]
+EPI_BF16_ADD_POS = ENUMS["WJ_EPI_BF16_ADD_POS"]
 GROUP_STATS_SPLIT = _abi.DEFINES["WJ_GROUP_STATS_SPLIT"]
 COLSUM_GROUP_MAX = _abi.DEFINES["WJ_COLSUM_GROUP_MAX"]
 
