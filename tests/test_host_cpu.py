@@ -234,7 +234,32 @@ def test_workspace_query():
     assert ops.workspace_bytes("wj_masked_mse", B=256, G=4, T=200) == (2 + 204800) * 4
     from wavjepa_amd import _abi
     lib = _abi.load()
-    assert lib.wj_workspace_bytes(b"wj_gemm_bf16", b"x") == 0 and lib.wj_workspace_bytes(b"nope", b"x") == -1
+    assert lib.wj_workspace_bytes(b"nope", b"x") == -1
+    # wj_gemm_bf16 (round 5): scratch for the K-split pairs -- only for row-form WJ_EPI_BF16 problems of 33..128 output tiles with
+    # N % 256 == 0, K % 256 == 0, K >= 1536: [tiles][2] flags padded to 4 KiB + two roles x four waves' accumulators per tile
+    gemm = dict(lda=3072, ldb=3072, ldc=768, epilogue=ops.EPI_BF16)
+    assert ops.workspace_bytes("wj_gemm_bf16", M=9945, N=768, K=3072, **gemm) == 4096 + 117 * 2 * 4 * 32 * 64 * 16
+    assert ops.workspace_bytes("wj_gemm_bf16", M=9945, N=768, K=768, **gemm) == 0            # short K: the exchange costs more than it saves
+    assert ops.workspace_bytes("wj_gemm_bf16", M=51200, N=768, K=3072, **gemm) == 0          # 600 tiles: the persistent schedule
+    assert ops.workspace_bytes("wj_gemm_bf16", M=9945, N=768, K=3072, **dict(gemm, epilogue=ops.EPI_ADD_F32)) == 0
+    assert ops.workspace_bytes("wj_gemm_bf16", M=9945, N=768, K=3072, b_trans=1, **gemm) == 0
+    assert ops.workspace_bytes("wj_mask_scatter_fill_pos_bwd", B=256, T=200, D=384, G=4) == ops.scatter_fill_bwd_partial_rows(256, 200) * 384 * 4
+
+
+def test_engine_pair_rule_matches_the_library():
+    """engine._pair_pays (which dgrads take the row form because the library will run them as K-split pairs) must agree with the
+    library's own eligibility rule (wj_workspace_bytes > 0) on every shape of a grid -- two copies of one rule, kept honest."""
+    from wavjepa_amd import ops
+    from wavjepa_amd.engine import JepaEngine
+
+    class Probe:
+        pair_split = True
+        PAIR_TILES = JepaEngine.PAIR_TILES
+    for M in (900, 4000, 8300, 9945, 12000, 16384, 32768, 33000):
+        for N in (256, 384, 512, 768, 1024):
+            for K in (256, 768, 1280, 1536, 2304, 3072):
+                want = ops.workspace_bytes("wj_gemm_bf16", M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BF16) > 0
+                assert JepaEngine._pair_pays(Probe, M, N, K) == want, (M, N, K)
 
 
 def test_conv_geometry_and_mask_plan():
