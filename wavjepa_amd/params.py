@@ -95,14 +95,14 @@ class FlatParams:
 
     def owns(self, module: nn.Module) -> bool:
         """True while the module's parameters still alias the flat buffers (e.g. not after .to()/.cuda())."""
-        params = dict(module.named_parameters())
+        # (two direct look-ups: building dict(named_parameters()) walked all 457 tensors, ~1 ms of host time, five times per step)
         s = self.slots[-1]
-        if params[s.name].data_ptr() != self.p32.data_ptr() + 4 * s.offset:
+        if module.get_parameter(s.name).data_ptr() != self.p32.data_ptr() + 4 * s.offset:
             return False
         if not self.tslots:
             return True
         t = self.tslots[-1]
-        return params[t.name].data_ptr() == self.t32.data_ptr() + 4 * t.offset
+        return module.get_parameter(t.name).data_ptr() == self.t32.data_ptr() + 4 * t.offset
 
     def attach_grads(self) -> None:
         """(Re-)expose the flat gradient buffer as every parameter's .grad (zero_grad(set_to_none) drops them)."""
