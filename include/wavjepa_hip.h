@@ -252,7 +252,8 @@ int wj_ln_bwd_partial_rows(int M, int D);
  * student (jepa.py:397,452, mask = ctx_masks), the predictor (jepa.py:438, mask = ctx_and_target_masks) and the
  * teacher (jepa.py:256-258, no mask).   qkv: bf16 [B][T][3*H*hd] packed q|k|v;  key_mask: u8 [B][T], nonzero =
  * key NOT attended, or NULL;  out: bf16 [B][T][H*hd];  lse: f32 [B][H][T] (log-sum-exp of scaled scores).
- * hd in {32, 64};  T <= 416 (three instantiations: <= 128, <= 224, <= 416 tokens).
+ * hd in {32, 64};  T <= 416 (three instantiations: <= 128, <= 224, <= 416 tokens).  hd = 16 (T <= 224; BASELINE config 1's predictor,
+ * 4 heads of 16): computed in the 32-wide geometry with the upper half of the head dimension zero, scale 1/sqrt(16).
  * Ragged form (seq_off != NULL): the B sequences are PACKED back to back, sequence b = rows [seq_off[b], seq_off[b+1])
  * of qkv / out / dout / dqkv, every key attended (key_mask must be NULL), T = upper bound of the lengths, and
  * lse: f32 [rows][H].  This is how the student / predictor run on their visible tokens only: a key-masked query row

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 SMALL_SPEC = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)]
 SMALL = dict(conv_spec=SMALL_SPEC, d_enc=128, h_enc=2, l_enc=2, d_dec=64, h_dec=2, l_dec=2, top_k=2)
+SMALL16 = dict(SMALL, h_enc=4, h_dec=4)      # BASELINE config 1's head layout: student 4 x 32, predictor 4 x 16
 BASE = dict(conv_spec=list(J.WAVJEPA_CONV_SPEC), d_enc=768, h_enc=12, l_enc=12, d_dec=384, h_dec=12, l_dec=12, top_k=8)
 
 
@@ -115,10 +116,12 @@ def group_of(name):
 # doubles any error fails.
 ACT_TOL = {"base": dict(local_features=8.6e-3, targets=8.6e-3, contextual_features=8.6e-3, preds=7.0e-3),
            "small": dict(local_features=9.2e-3, targets=9.6e-3, contextual_features=1.08e-2, preds=7.5e-3)}
-GRAD_TOL = {"base": 1.0e-2, "small": 1.5e-2}
+ACT_TOL["small16"] = ACT_TOL["small"]
+GRAD_TOL = {"base": 1.0e-2, "small": 1.5e-2, "small16": 1.5e-2}
 
 
 @pytest.mark.parametrize("cfg_name,n,ragged", [("small", 4, True), ("small", 4, False), ("small", 1, True), ("small", 1, False),
+                                                ("small16", 4, True), ("small16", 4, False),  # 16-wide predictor heads (config 1)
                                                 ("base", 2, True), ("base", 2, False),       # n = 1: a single clip (fewer rows than one GEMM tile)
                                                 ("base", 64, True)])
 def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
@@ -128,7 +131,7 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     persistent eight-phase GEMM: in_proj, linear1 + GELU, out_proj / linear2 stay on the one-tile schedules), predictor
     M ~ 21 600 (persistent in_proj / linear1 / MUL_GELU_GRAD, half-width N = 384 items), grouped weight gradients at their real
     split factors, ragged arena sized from the row counts -- end to end against the oracle, not only op by op."""
-    cfg = SMALL if cfg_name == "small" else BASE
+    cfg = {"small": SMALL, "small16": SMALL16, "base": BASE}[cfg_name]
     m, P = build(cfg)
     m._ensure_engine().ragged = ragged
     ctx, tgt, vis = masks(golden_dir, n)

@@ -530,7 +530,9 @@ def ref_attention(qkv, H, mask):
 
 @pytest.mark.parametrize("B,T,H,hd", [(3, 200, 12, 64), (4, 200, 12, 32), (2, 49, 4, 64), (2, 24, 2, 32), (1, 224, 2, 64),
                                       (2, 400, 12, 64), (2, 400, 12, 32), (1, 416, 2, 64), (2, 225, 2, 32),
-                                      (2, 129, 4, 32), (2, 150, 4, 32), (2, 192, 2, 32), (2, 193, 2, 32), (2, 150, 2, 64)])
+                                      (2, 129, 4, 32), (2, 150, 4, 32), (2, 192, 2, 32), (2, 193, 2, 32), (2, 150, 2, 64),
+                                      # 16-wide heads (BASELINE config 1's predictor: 4 x 16): the 32-wide geometry, upper half zeros
+                                      (3, 200, 4, 16), (2, 49, 4, 16), (2, 128, 2, 16), (2, 150, 4, 16), (1, 224, 6, 16)])
 def test_attention_fwd_bwd(ops, B, T, H, hd):
     D = H * hd
     qkv = rnd(B, T, 3 * D, dtype=torch.bfloat16, seed=30)
@@ -539,7 +541,7 @@ def test_attention_fwd_bwd(ops, B, T, H, hd):
     mask[:, 0] = False
     mask = mask.to(dev())
     mask_u8 = mask.to(torch.uint8).contiguous()
-    out = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev())
+    out = torch.full((B, T, D), float("nan"), dtype=torch.bfloat16, device=dev())
     lse = torch.empty(B, H, T, device=dev())
     ops.attn_fwd(qkv, out, B=B, T=T, H=H, hd=hd, key_mask=mask_u8, lse=lse)
     x = qkv.float().requires_grad_(True)
@@ -570,7 +572,7 @@ def test_attention_no_mask(ops):
     assert relerr(out.float(), ref) < 8e-3
 
 
-@pytest.mark.parametrize("B,T,H,hd", [(5, 200, 12, 64), (8, 200, 12, 32), (3, 40, 2, 32)])
+@pytest.mark.parametrize("B,T,H,hd", [(5, 200, 12, 64), (8, 200, 12, 32), (3, 40, 2, 32), (6, 200, 4, 16), (3, 40, 4, 16)])
 def test_attention_ragged_matches_key_masked(ops, B, T, H, hd):
     """Ragged form (packed visible rows, every key attended) == the dense key-masked form on the visible rows, and both
     == plain softmax attention over each sequence's visible tokens."""

@@ -1,4 +1,4 @@
-// Key-masked multi-head self-attention for short sequences (T <= 224, head dim 32/64) on gfx950.
+// Key-masked multi-head self-attention for short sequences (T <= 224, head dim 32/64; 16 in the 32-wide geometry) on gfx950.
 //
 // One workgroup (4 waves) per (batch, head).  The whole K/V (forward) or K,V then Q,dO (backward) of that head
 // lives in LDS as ONE padded image per matrix ([rows][hd*2+32 bytes]) that serves both the row reads
@@ -30,7 +30,7 @@ template <int HD> struct Img {
 // Copy rows [0,T) of TWO [T][ld] bf16 matrices (HD columns each) into their padded LDS images; rows [T,KP) are zero.
 // All global loads of a thread are issued before its first LDS store (a load->store loop would serialise one HBM/L2
 // round trip per iteration: ~13 of them for a 200 x 64 head).
-template <int HD, int NWAVES, int MT = MAX_TILES>
+template <int HD, int NWAVES, int MT = MAX_TILES, int HG = HD>
 struct RowRegs {
     static constexpr int CH = Img<HD>::CH, RS = Img<HD>::RS;
     static constexpr int MAXI = (MT * 16 * CH + NWAVES * 64 - 1) / (NWAVES * 64);
@@ -42,7 +42,7 @@ struct RowRegs {
             const int idx = threadIdx.x + it * (NWAVES * 64);
             const int row = idx / CH, c = idx - row * CH;
             v0[it] = v1[it] = make_uint4(0, 0, 0, 0);
-            if (row < T) {
+            if (row < T && c * 8 < HG) {     // (HG < HD: a 16-wide head in the 32-wide geometry, its upper half zeros)
                 v0[it] = *reinterpret_cast<const uint4*>(src0 + (long)row * ld0 + c * 8);
                 v1[it] = *reinterpret_cast<const uint4*>(src1 + (long)row * ld1 + c * 8);
             }
@@ -61,10 +61,10 @@ struct RowRegs {
     }
 };
 
-template <int HD, int NWAVES, int MT = MAX_TILES>
+template <int HD, int NWAVES, int MT = MAX_TILES, int HG = HD>
 __device__ __forceinline__ void fill_images2(char* img0, const bf16_t* __restrict__ src0, long ld0, char* img1,
                                              const bf16_t* __restrict__ src1, long ld1, int T, int KP) {
-    RowRegs<HD, NWAVES, MT> r;
+    RowRegs<HD, NWAVES, MT, HG> r;
     r.load(src0, ld0, src1, ld1, T);
     r.store(img0, img1, KP);
 }
@@ -76,13 +76,13 @@ __device__ __forceinline__ bf16x8 row_frag(const char* img, int rbase, int ks, i
     return *reinterpret_cast<const bf16x8*>(img + (rbase + i) * Img<HD>::RS + (ks * 4 + g) * 16);
 }
 // Same operand straight from global memory (each wave needs its own 16 rows exactly once).
-__device__ __forceinline__ bf16x8 row_frag_global(const bf16_t* __restrict__ src, long ld, int rbase, int T, int ks, int lane) {
+__device__ __forceinline__ bf16x8 row_frag_global(const bf16_t* __restrict__ src, long ld, int rbase, int T, int ks, int lane, int hg) {
     const int i = lane & 15, g = lane >> 4;
     const int row = rbase + i;
     bf16x8 z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = f2bf(0.f);
-    if (row < T) z = *reinterpret_cast<const bf16x8*>(src + (long)row * ld + ks * 32 + 8 * g);
+    if (row < T && ks * 32 + 8 * g < hg) z = *reinterpret_cast<const bf16x8*>(src + (long)row * ld + ks * 32 + 8 * g);
     return z;
 }
 // MFMA A-operand with k = sequence (32-row chunk c) and rows = head-dim slice [d0, d0+16), matched to a B operand
@@ -126,11 +126,11 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // MT = most 16-row tiles a sequence may have (14: T <= 224; 8: T <= 128, fewer live registers -> more waves per SIMD)
-template <int HD, int NWF, int MT>
+template <int HD, int NWF, int MT, int HG = HD>
 __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 : 6) : (MT == 12 ? 4 : 2))) void attn_fwd_kernel(wj_attn_fwd_args a) {
-    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
+    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HG / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int H = a.H, D = H * HD;
+    const int H = a.H, D = H * HG;        // HG: the head width in memory (16 runs in the 32-wide geometry)
     // the heads of one sequence read interleaved 2*HD-byte slices of the same rows: keep them on ONE XCD so that the
     // other half of every 128-B line is an L2 hit (round-robin dispatch would spread them over all eight L2s: PMC showed
     // the hd = 32 predictor fetching 1.8x (fwd) / 2.6x (bwd) its algorithmic bytes)
@@ -149,11 +149,11 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const long ld = 3L * D;
-    const bf16_t* base = (const bf16_t*)a.qkv + row0 * ld + h * HD;
+    const bf16_t* base = (const bf16_t*)a.qkv + row0 * ld + h * HG;
     bf16x8 qf[KS];                       // this wave's first query tile: in flight while K / V are staged
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, wave * 16, T, ks, lane);
-    fill_images2<HD, NWF, MT>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = row_frag_global(base, ld, wave * 16, T, ks, lane, HG);
+    fill_images2<HD, NWF, MT, HG>(kimg, base + D, ld, vimg, base + 2 * D, ld, T, KP);
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
     for (int k = threadIdx.x; k < KP; k += blockDim.x)
         madd[k] = (k < T && !(km && km[k])) ? 0.f : -INFINITY;
@@ -162,11 +162,11 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
     // softmax in the exp2 domain on the RAW scores: max over s, then p = exp2(s * (scale * log2 e) - max * (scale * log2 e)) -- one
     // fma + v_exp_f32 per score.  (A wave-uniform branch that skipped the mask on tiles without one put a taken branch between an
     // MFMA and the first VALU read of its result; hipcc left one wait state there and the kernel returned run-dependent sums.)
-    const float scale = rsqrtf((float)HD), scale2 = scale * LOG2E;
+    const float scale = rsqrtf((float)HG), scale2 = scale * LOG2E;
     for (int qt = wave; qt < nkt; qt += NWF) {
         bf16x8 qn[KS];                   // next tile's fragments: issued now, consumed at the end of this iteration
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NWF) * 16, (qt + NWF < nkt) ? T : 0, ks, lane);
+        for (int ks = 0; ks < KS; ++ks) qn[ks] = row_frag_global(base, ld, (qt + NWF) * 16, (qt + NWF < nkt) ? T : 0, ks, lane, HG);
         f32x4 s[MT];
         float mx = -INFINITY;
         // key tiles go in PAIRS (one 32-row chunk of the image; the second tile of the last chunk may be all padding: zero K rows
@@ -223,13 +223,13 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
         }
         const int q = qt * 16 + i;
         if (q < T) {
-            bf16_t* op = (bf16_t*)a.out + (row0 + q) * D + h * HD;
+            bf16_t* op = (bf16_t*)a.out + (row0 + q) * D + h * HG;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 ov;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ov[r] = f2bf(o[dt][r]);
-                *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) = ov;
+                if (dt * 16 < HG) *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) = ov;
             }
             if (a.lse && g == 0)
                 a.lse[a.seq_off ? (row0 + q) * H + h : ((long)b * H + h) * T + q] = sum > 0.f ? fmaf(msafe, scale, __logf(sum)) : INFINITY;
@@ -240,11 +240,11 @@ __global__ __launch_bounds__(NWF * 64, MT == 14 ? 4 : (MT == 8 ? (HD == 64 ? 4 :
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int HD, int NWB, int MT>
+template <int HD, int NWB, int MT, int HG = HD>
 __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void attn_bwd_kernel(wj_attn_bwd_args a) {
-    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16;
+    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HG / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int H = a.H, D = H * HD;
+    const int H = a.H, D = H * HG;        // HG: the head width in memory (16 runs in the 32-wide geometry)
     const int wg = xcd_remap(blockIdx.x, gridDim.x);   // heads of one sequence on one XCD (see the forward)
     const int b = wg / H, h = wg - b * H;
     int T = a.T;
@@ -264,17 +264,17 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const long ld = 3L * D;
-    const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * ld + h * HD;
-    const bf16_t* dO = (const bf16_t*)a.dout + row0 * D + h * HD;
-    const bf16_t* O = (const bf16_t*)a.out + row0 * D + h * HD;
-    bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HD;
+    const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * ld + h * HG;
+    const bf16_t* dO = (const bf16_t*)a.dout + row0 * D + h * HG;
+    const bf16_t* O = (const bf16_t*)a.out + row0 * D + h * HG;
+    bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HG;
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
-    fill_images2<HD, NWB, MT>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
+    fill_images2<HD, NWB, MT, HG>(img0, qkv + D, ld, img1, qkv + 2 * D, ld, T, KP);
     // short sequences: phase B's Q / dO rows are fetched NOW (a few registers per thread) and only parked in LDS once phase A
     // is done with the K / V images -- their global latency hides behind the statistics loop and phase A
     constexpr bool EARLY = MT <= 8 && HD == 32;   // (the 64-wide head has no registers to spare at 3 waves per SIMD)
-    RowRegs<HD, NWB, MT> nxt;
+    RowRegs<HD, NWB, MT, HG> nxt;
     if constexpr (EARLY) nxt.load(qkv, ld, dO, D, T);
     for (int r = threadIdx.x; r < KP; r += blockDim.x) {
         float l = INFINITY, dl = 0.f, kv = 0.f;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
             l = a.lse[a.seq_off ? (row0 + r) * H + h : ((long)b * H + h) * T + r];
             kv = (km && km[r]) ? 0.f : 1.f;
 #pragma unroll
-            for (int c = 0; c < HD / 8; ++c) {
+            for (int c = 0; c < HG / 8; ++c) {
                 const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (long)r * D + c * 8);
                 const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (long)r * D + c * 8);
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
         lse_s[r] = l; delta[r] = dl; kvalid[r] = kv;
     }
     __syncthreads();
-    const float scale = rsqrtf((float)HD);
+    const float scale = rsqrtf((float)HG);
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- phase A: dQ for 16 queries per wave iteration (queries on the lane, keys on the accumulator rows)
@@ -302,15 +302,15 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
     bf16x8 qf[KS], dof[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = row_frag_global(qkv, ld, wave * 16, T, ks, lane);
-        dof[ks] = row_frag_global(dO, D, wave * 16, T, ks, lane);
+        qf[ks] = row_frag_global(qkv, ld, wave * 16, T, ks, lane, HG);
+        dof[ks] = row_frag_global(dO, D, wave * 16, T, ks, lane, HG);
     }
     for (int qt = wave; qt < nt; qt += NWB) {
         bf16x8 qn[KS], don[KS];          // prefetch of the next query tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qn[ks] = row_frag_global(qkv, ld, (qt + NWB) * 16, (qt + NWB < nt) ? T : 0, ks, lane);
-            don[ks] = row_frag_global(dO, D, (qt + NWB) * 16, (qt + NWB < nt) ? T : 0, ks, lane);
+            qn[ks] = row_frag_global(qkv, ld, (qt + NWB) * 16, (qt + NWB < nt) ? T : 0, ks, lane, HG);
+            don[ks] = row_frag_global(dO, D, (qt + NWB) * 16, (qt + NWB < nt) ? T : 0, ks, lane, HG);
         }
         const float my_lse = lse_s[qt * 16 + i], my_delta = delta[qt * 16 + i];
         f32x4 dq[DT];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
                 bf16x4 ov;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ov[r] = f2bf(dq[dt][r]); csq[dt][r] += bf2f(ov[r]); }
-                *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
+                if (dt * 16 < HG) *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
             }
         }
 #pragma unroll
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
     }
     __syncthreads();
     if constexpr (EARLY) nxt.store(img0, img1, KP);
-    else fill_images2<HD, NWB, MT>(img0, qkv, ld, img1, dO, D, T, KP);
+    else fill_images2<HD, NWB, MT, HG>(img0, qkv, ld, img1, dO, D, T, KP);
     __syncthreads();
 
     // ---- phase B: dK, dV for 16 keys per wave iteration (keys on the lane, queries on the accumulator rows)
@@ -380,15 +380,15 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = row_frag_global(qkv + D, ld, wave * 16, T, ks, lane);
-        vf[ks] = row_frag_global(qkv + 2 * D, ld, wave * 16, T, ks, lane);
+        kf[ks] = row_frag_global(qkv + D, ld, wave * 16, T, ks, lane, HG);
+        vf[ks] = row_frag_global(qkv + 2 * D, ld, wave * 16, T, ks, lane, HG);
     }
     for (int kt = wave; kt < nt; kt += NWB) {
         bf16x8 kn[KS], vn[KS];           // prefetch of the next key tile
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kn[ks] = row_frag_global(qkv + D, ld, (kt + NWB) * 16, (kt + NWB < nt) ? T : 0, ks, lane);
-            vn[ks] = row_frag_global(qkv + 2 * D, ld, (kt + NWB) * 16, (kt + NWB < nt) ? T : 0, ks, lane);
+            kn[ks] = row_frag_global(qkv + D, ld, (kt + NWB) * 16, (kt + NWB < nt) ? T : 0, ks, lane, HG);
+            vn[ks] = row_frag_global(qkv + 2 * D, ld, (kt + NWB) * 16, (kt + NWB < nt) ? T : 0, ks, lane, HG);
         }
         const float my_kv = kvalid[kt * 16 + i];
         f32x4 dk[DT], dv[DT];
@@ -438,8 +438,10 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
                     ok[r] = f2bf(dk[dt][r]); ov[r] = f2bf(dv[dt][r]);
                     csk[dt][r] += bf2f(ok[r]); csv[dt][r] += bf2f(ov[r]);
                 }
-                *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
-                *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
+                if (dt * 16 < HG) {
+                    *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
+                    *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
+                }
             }
         }
 #pragma unroll
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
         // into the same 3*D addresses cost 70-80 us per launch)
         for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) {
             const int part = x / HD, d = x - part * HD;
-            a.dbias_ws[(long)b * 3 * D + part * D + h * HD + d] = bsum[x];
+            if (d < HG) a.dbias_ws[(long)b * 3 * D + part * D + h * HG + d] = bsum[x];
         }
     }
 }
@@ -476,12 +478,12 @@ __global__ __launch_bounds__(NWB * 64, MT > 14 ? 2 : (HD == 64 ? 3 : 4)) void at
 //   * the K / V fragments are written to the LDS images for phase A and stay in registers as phase B's own-tile operands,
 //   * the Q / dO fragments are phase A's own-tile operands and are written to the images once phase A is done,
 //   * delta = rowsum(dO . O) falls out of the dO / O fragments with two cross-lane adds.
-template <int HD, int NWB, int MT, bool MASKED>
+template <int HD, int NWB, int MT, bool MASKED, int HG = HD>
 __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kernel(wj_attn_bwd_args a) {
-    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HD / 16, TPW = MT / NWB;
+    constexpr int RS = Img<HD>::RS, KS = HD / 32, DT = HG / 16, TPW = MT / NWB;
     static_assert(MT % NWB == 0, "tiles are dealt to waves round-robin");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int H = a.H, D = H * HD;
+    const int H = a.H, D = H * HG;        // HG: the head width in memory (16 runs in the 32-wide geometry)
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int b = wg / H, h = wg - b * H;
     int T = a.T;
@@ -501,10 +503,10 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const long ld = 3L * D;
-    const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * ld + h * HD;
-    const bf16_t* dO = (const bf16_t*)a.dout + row0 * D + h * HD;
-    const bf16_t* O = (const bf16_t*)a.out + row0 * D + h * HD;
-    bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HD;
+    const bf16_t* qkv = (const bf16_t*)a.qkv + row0 * ld + h * HG;
+    const bf16_t* dO = (const bf16_t*)a.dout + row0 * D + h * HG;
+    const bf16_t* O = (const bf16_t*)a.out + row0 * D + h * HG;
+    bf16_t* dqkv = (bf16_t*)a.dqkv + row0 * ld + h * HG;
     const uint8_t* km = a.key_mask ? a.key_mask + (long)(b / a.mask_group) * T : nullptr;
 
     bf16x8 kfr[TPW][KS], vfr[TPW][KS], qfr[TPW][KS], dofr[TPW][KS];
@@ -516,11 +518,11 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
             const int rb = (wave + t * NWB) * 16, row = rb + i;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                kfr[t][ks] = row_frag_global(qkv + D, ld, rb, T, ks, lane);
-                vfr[t][ks] = row_frag_global(qkv + 2 * D, ld, rb, T, ks, lane);
-                qfr[t][ks] = row_frag_global(qkv, ld, rb, T, ks, lane);
-                dofr[t][ks] = row_frag_global(dO, D, rb, T, ks, lane);
-                ofr[t][ks] = row_frag_global(O, D, rb, T, ks, lane);
+                kfr[t][ks] = row_frag_global(qkv + D, ld, rb, T, ks, lane, HG);
+                vfr[t][ks] = row_frag_global(qkv + 2 * D, ld, rb, T, ks, lane, HG);
+                qfr[t][ks] = row_frag_global(qkv, ld, rb, T, ks, lane, HG);
+                dofr[t][ks] = row_frag_global(dO, D, rb, T, ks, lane, HG);
+                ofr[t][ks] = row_frag_global(O, D, rb, T, ks, lane, HG);
             }
             lse_r[t] = INFINITY; kv_r[t] = 0.f;
             if (row < T) {
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
     // applied once to the dQ / dK accumulators (as the flash kernels do) instead of to every dS element.
     // Without a key mask nothing needs masking at all: K / V rows >= T are zero in the images, so a padding key adds 0 to dQ, and the
     // dK / dV rows of padding keys are never stored; padding QUERIES have lse = +inf, p = 0.
-    const float scale = rsqrtf((float)HD), scale2 = scale * LOG2E;
+    const float scale = rsqrtf((float)HG), scale2 = scale * LOG2E;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- phase A: dQ of this wave's query tiles
@@ -597,6 +599,9 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
                         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<HD>(img0, c, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
                 }
             }
+            // (one output tile per accumulator set: its last MFMA sits right in front of the loop's exit branch, and hipcc leaves the VALU
+            // read behind that branch one wait state short -- tools/mfma_hazard_scan.py)
+            if constexpr (HG < HD) asm volatile("s_nop 7" ::: "memory");
             const int q = qt * 16 + i;
             if (q < T) {
 #pragma unroll
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
                     bf16x4 ov;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { ov[r] = f2bf(dq[dt][r] * scale); csq[dt][r] += bf2f(ov[r]); }
-                    *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
+                    if (dt * 16 < HG) *reinterpret_cast<bf16x4*>(dqkv + (long)q * ld + dt * 16 + 4 * g) = ov;
                 }
             }
         }
@@ -678,6 +683,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
                     }
                 }
             }
+            if constexpr (HG < HD) asm volatile("s_nop 7" ::: "memory");
             const int key = kt * 16 + i;
             if (key < T) {
 #pragma unroll
@@ -688,8 +694,10 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
                         ok[r] = f2bf(dk[dt][r] * scale); ov[r] = f2bf(dv[dt][r]);
                         csk[dt][r] += bf2f(ok[r]); csv[dt][r] += bf2f(ov[r]);
                     }
-                    *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
-                    *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
+                    if (dt * 16 < HG) {
+                        *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + D + dt * 16 + 4 * g) = ok;
+                        *reinterpret_cast<bf16x4*>(dqkv + (long)key * ld + 2 * D + dt * 16 + 4 * g) = ov;
+                    }
                 }
             }
         }
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(NWB * 64, HD == 64 ? 3 : 4) void attn_bwd_frag_kern
         __syncthreads();
         for (int x = threadIdx.x; x < 3 * HD; x += blockDim.x) {
             const int part = x / HD, d = x - part * HD;
-            a.dbias_ws[(long)b * 3 * D + part * D + h * HD + d] = bsum[x];
+            if (d < HG) a.dbias_ws[(long)b * 3 * D + part * D + h * HG + d] = bsum[x];
         }
     }
 }
@@ -725,9 +733,11 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
     if (!a || !a->qkv || !a->out) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES_LONG * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
-    if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    if (a->hd != 16 && a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    if (a->hd == 16 && a->T > MAX_TILES * 16) return WJ_ERR_UNSUPPORTED;      // (16-wide heads: the tiny configuration, T <= 224)
+    const int hdk = a->hd == 16 ? 32 : a->hd;             // a 16-wide head runs in the 32-wide geometry, the upper half of its K dimension zeros
     const int KP = ((a->T + 31) / 32) * 32;
-    const int lds = 2 * KP * (a->hd * 2 + 32) + KP * 4;
+    const int lds = 2 * KP * (hdk * 2 + 32) + KP * 4;
     dim3 grid(a->B * a->H);
     hipStream_t st = (hipStream_t)stream;
     static int once = set_lds(attn_fwd_kernel<64, NWF_LONG, 14>, 2 * 224 * 160 + 224 * 4) | set_lds(attn_fwd_kernel<32, NWF_LONG, 14>, 2 * 224 * 96 + 224 * 4) |
@@ -735,7 +745,11 @@ extern "C" int wj_attn_fwd(const wj_attn_fwd_args* a, void* stream) {
                       set_lds(attn_fwd_kernel<64, NWF_LONG, 26>, 2 * 416 * 160 + 416 * 4) | set_lds(attn_fwd_kernel<32, NWF_LONG, 26>, 2 * 416 * 96 + 416 * 4);
     (void)once;
     const bool shortseq = a->T <= 128;
-    if (a->T > MAX_TILES * 16) {     // 225 .. 416 tokens
+    if (a->hd == 16) {
+        if (shortseq) hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_SHORT, 8, 16>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
+        else if (a->T <= 192) hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_SHORT, 12, 16>), grid, dim3(NWF_SHORT * 64), lds, st, *a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_LONG, 14, 16>), grid, dim3(NWF_LONG * 64), lds, st, *a);
+    } else if (a->T > MAX_TILES * 16) {     // 225 .. 416 tokens
         if (a->hd == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, NWF_LONG, 26>), grid, dim3(NWF_LONG * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_fwd_kernel<32, NWF_LONG, 26>), grid, dim3(NWF_LONG * 64), lds, st, *a);
     } else if (a->hd == 64) {
@@ -757,10 +771,12 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
     if (!a || !a->qkv || !a->out || !a->dout || !a->lse || !a->dqkv) return WJ_ERR_ARG;
     if (a->B <= 0 || a->T <= 0 || a->T > MAX_TILES_LONG * 16 || a->H <= 0 || a->mask_group < 1) return WJ_ERR_ARG;
     if (a->seq_off && a->key_mask) return WJ_ERR_ARG;
-    if (a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    if (a->hd != 16 && a->hd != 32 && a->hd != 64) return WJ_ERR_UNSUPPORTED;
+    if (a->hd == 16 && a->T > MAX_TILES * 16) return WJ_ERR_UNSUPPORTED;
     if (a->dbias && !a->dbias_ws) return WJ_ERR_ARG;
+    const int hdk = a->hd == 16 ? 32 : a->hd;
     const int KP = ((a->T + 31) / 32) * 32;
-    const int lds = 2 * KP * (a->hd * 2 + 32) + 3 * KP * 4 + 3 * a->hd * 4;
+    const int lds = 2 * KP * (hdk * 2 + 32) + 3 * KP * 4 + 3 * hdk * 4;
     dim3 grid(a->B * a->H);
     hipStream_t st = (hipStream_t)stream;
     static int once = set_lds(attn_bwd_kernel<64, NWB64, 14>, 2 * 224 * 160 + 3 * 224 * 4 + 3 * 64 * 4) |
@@ -768,7 +784,17 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
                       set_lds(attn_bwd_kernel<64, NWB64, 26>, 2 * 416 * 160 + 3 * 416 * 4 + 3 * 64 * 4) |
                       set_lds(attn_bwd_kernel<32, NWB32, 26>, 2 * 416 * 96 + 3 * 416 * 4 + 3 * 32 * 4);
     (void)once;
-    if (a->T > MAX_TILES * 16) {     // 225 .. 416 tokens
+    if (a->hd == 16) {
+        if (a->T <= 128) {
+            if (a->key_mask) hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 8, true, 16>), grid, dim3(NWB32 * 64), lds, st, *a);
+            else hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 8, false, 16>), grid, dim3(NWB32 * 64), lds, st, *a);
+        } else if (a->T <= 192) {
+            if (a->key_mask) hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 12, true, 16>), grid, dim3(NWB32 * 64), lds, st, *a);
+            else hipLaunchKernelGGL((attn_bwd_frag_kernel<32, NWB32, 12, false, 16>), grid, dim3(NWB32 * 64), lds, st, *a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 14, 16>), grid, dim3(NWB32 * 64), lds, st, *a);
+        }
+    } else if (a->T > MAX_TILES * 16) {     // 225 .. 416 tokens
         if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 26>), grid, dim3(NWB64 * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 26>), grid, dim3(NWB32 * 64), lds, st, *a);
     } else if (a->T <= 128) {          // ragged student / predictor: at most 8 tiles (6 or 8 waves per workgroup measured 1.5-2x slower)

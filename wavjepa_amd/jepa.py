@@ -253,11 +253,10 @@ class JEPA(_ModuleBase):
             enc_c.update(num_layers=24)
         elif size == "tiny":
             # BASELINE config 1 (a build-defined size, the reference knows base / large only): 2-layer student d = 128,
-            # 2-layer predictor d = 64.  The survey's predictor has 4 heads = head dim 16; the attention kernels are built for head dims
-            # 32 / 64 (the base / large models), so the tiny predictor runs 2 heads of 32 -- the same widths and GEMM shapes.
+            # 2-layer predictor d = 64 with 4 heads (head dim 16: wj_attn_* run it in their 32-wide geometry).
             enc_l.update(nhead=4, d_model=128, dim_feedforward=512)
             enc_c.update(num_layers=2)
-            dec_l.update(nhead=2, d_model=64, dim_feedforward=256)
+            dec_l.update(nhead=4, d_model=64, dim_feedforward=256)
             dec_c.update(num_layers=2)
             self.hparams["average_top_k_layers"] = min(int(average_top_k_layers), 2)
         self.n_encoder_heads = enc_l["nhead"]
