@@ -11,6 +11,7 @@
 //   X1[q] = sum_t x_{t,q},  YX[q] = sum_t y_t x_{t,q}      gradient-independent: accumulated by the FORWARD statistics pass.
 // So the backward is ONE pass over the listed active rows (A1, A2, S) plus a tiny per-(n,c) finalize; the dense part of
 // GroupNorm's backward never touches the activation-sized tensors.
+#include <string.h>
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
 
@@ -115,6 +116,92 @@ inline int stats_tcs(int N, int L_out, int C_in) {
     const int cap = 2176 / (C_in > 0 ? C_in : 1) / 32 * 32;           // the chunk's audio samples live in LDS (bf16, C_in x ~5 tcs): <= ~44 KB
     return tcs > cap ? (cap < 32 ? 32 : cap) : tcs;
 }
+// ---- pass 1, algebraic form (round 5; WJ_CONV0_STATS=mfma selects the pass below instead).  Everything pass 1 produces is a sum over
+// the time axis of products of the conv output y_t = sum_k w_k x_{t,k} with 1, y_t or a patch element x_{t,q}:
+//     sum_t y_t = w . X1,   sum_t y_t^2 = w^T X2 w,   sum_t y_t x_{t,q} = (w^T X2)_q,   with X1 = sum_t x_t, X2 = sum_t x_t x_t^T
+// -- a TAPS-vector and a TAPS x TAPS matrix per CLIP, independent of the 512 channels: 0.7 MFLOP per clip instead of a pass that computes
+// the whole conv output a first time only to sum it (256 us of the step's exposed start, VALU-bound on rounding and summing 421 M values).
+// In DOUBLE precision throughout: a high-pass filter on a smooth signal makes w^T X2 w a difference of terms 1e4-1e6 times its size
+// (fp32 Grams lose the variance there; the products of bf16 samples are exact in either precision, the sums are not).
+// What changes: these are the sums of the UNROUNDED conv output, the pass below sums the bf16-rounded one as the reference's GroupNorm
+// sees it.  The rounding errors of 6430 values average out: the means differ by <= ~1.5e-4 of the channel's standard deviation, rstd by a
+// few 1e-5 relative (tests/test_ops_gpu.py::test_conv0_fwd_bwd) -- 1/30 and 1/100 of one bf16 step of the activations they shift and
+// scale, and on the fp32 side of the reference's own values.
+// conv0_gram_kernel: one workgroup per (chunk of TCS time steps, clip) STORES part[n][chunk][TAPS | TAPS * TAPS]; conv0_fold_f64_kernel adds
+// the chunks in order (no atomics: bit-reproducible).  conv0_stats_from_gram_kernel: one thread per (clip, channel).
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv0_gram_kernel(const bf16_t* __restrict__ audio, double* __restrict__ part, Geo g, int span, int TCS) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t xa[];   // [C_in][span] samples of this chunk (0 past the clip)
+    constexpr int G = TAPS + TAPS * TAPS;
+    __shared__ double red[4][G];
+    const int n = blockIdx.y, t0 = blockIdx.x * TCS;
+    for (int ci = 0; ci < g.C_in; ++ci)
+        for (int i = threadIdx.x; i < span; i += 256) {
+            const long src = (long)t0 * g.stride + i;
+            xa[ci * span + i] = src < g.L ? audio[(long)n * g.clip_stride + (long)ci * g.L + src] : f2bf(0.f);
+        }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tcount = min(TCS, g.L_out - t0);
+    for (int p = lane; p < G; p += 64) {
+        const bool one = p < TAPS;
+        const int qa = one ? p : (p - TAPS) / TAPS, qb = one ? 0 : (p - TAPS) - qa * TAPS;
+        const int ca = qa / g.k, cb = qb / g.k;
+        const int offa = ca * span + (qa - ca * g.k), offb = cb * span + (qb - cb * g.k);
+        double acc = 0.0;
+        for (int t = wave; t < tcount; t += 4) {
+            const float a = bf2f(xa[offa + t * g.stride]);
+            const float b = one ? 1.0f : bf2f(xa[offb + t * g.stride]);
+            acc += (double)(a * b);                    // the product of two bf16 values is exact in fp32
+        }
+        red[wave][p] = acc;
+    }
+    __syncthreads();
+    double* o = part + ((long)n * gridDim.x + blockIdx.x) * G;
+    for (int p = threadIdx.x; p < G; p += 256) o[p] = (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+}
+
+// out[n][i] = sum over chunks, in chunk order, of part[n][chunk][i]
+__global__ __launch_bounds__(256) void conv0_fold_f64_kernel(const double* __restrict__ part, int chunks, int rec, double* __restrict__ out) {
+    const int n = blockIdx.y;
+    const double* src = part + (long)n * chunks * rec;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rec; i += gridDim.x * 256) {
+        double s = 0.0;
+        for (int ch = 0; ch < chunks; ++ch) s += src[(long)ch * rec + i];
+        out[(long)n * rec + i] = s;
+    }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv0_stats_from_gram_kernel(const double* __restrict__ gram, const bf16_t* __restrict__ wsrc,
+                                                                    float* __restrict__ sums, float* __restrict__ yx, float* __restrict__ x1,
+                                                                    Geo g) {
+    constexpr int G = TAPS + TAPS * TAPS;
+    __shared__ double gs[G];
+    const int n = blockIdx.y;
+    for (int p = threadIdx.x; p < G; p += 256) gs[p] = gram[(long)n * G + p];
+    __syncthreads();
+    if (x1 && blockIdx.x == 0 && threadIdx.x < TAPS) x1[(long)n * TAPS + threadIdx.x] = (float)gs[threadIdx.x];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.C) return;
+    double w[TAPS];
+#pragma unroll
+    for (int q = 0; q < TAPS; ++q) w[q] = (double)bf2f(wsrc[(long)c * TAPS + q]);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < TAPS; ++q) s1 += w[q] * gs[q];
+#pragma unroll
+    for (int q = 0; q < TAPS; ++q) {
+        double v = 0.0;                                  // (w^T X2)_q = sum_t y_t x_{t,q}
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) v += w[k] * gs[TAPS + k * TAPS + q];
+        s2 += v * w[q];
+        if (yx) yx[((long)n * g.C + c) * TAPS + q] = (float)v;
+    }
+    sums[((long)n * g.C + c) * 2] = (float)s1;
+    sums[((long)n * g.C + c) * 2 + 1] = (float)fmax(s2, 0.0);
+}
+
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv0_stats_mfma_kernel(const bf16_t* __restrict__ audio, const bf16_t* __restrict__ wsrc,
                                                                float* __restrict__ part, int want_yx, Geo g, int span, int TCS) {
@@ -551,10 +638,24 @@ void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStrea
     float* sums = a->workspace;                       // [N][C][2] folded statistics
     float* part = a->workspace + 2L * a->N * a->C;    // [N][chunks][rec] partial records
     const int span = (TCS - 1) * a->stride + a->k;
-    hipLaunchKernelGGL(conv0_stats_mfma_kernel<TAPS>, dim3(chunks, a->N), dim3(256), (size_t)a->C_in * span * sizeof(bf16_t), s,
-                       (const bf16_t*)a->audio, (const bf16_t*)a->w, part, want_yx, g, span, TCS);
-    hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
-                       sums, 2L * a->C, a->yx, (long)a->C * TAPS, a->x1, (const int32_t*)nullptr, 1);
+    static const int gram_mode = [] { const char* e = getenv("WJ_CONV0_STATS"); return (e && !strcmp(e, "mfma")) ? 0 : 1; }();
+    constexpr long G = TAPS + (long)TAPS * TAPS;
+    // (the partial Grams -- doubles -- and their fold share the scratch the pass below sizes for its partial records: they fit unless
+    // C < ~4 TAPS)
+    if (gram_mode && 2 * G * (chunks + 1) <= (long)chunks * fwd_record<TAPS>(a->C, 1)) {
+        double* gpart = reinterpret_cast<double*>(part);          // [N][chunks][G]   (part is 8-byte aligned: 2 N C floats past a 256-byte-aligned base)
+        double* gfold = gpart + (long)a->N * chunks * G;          // [N][G]
+        hipLaunchKernelGGL(conv0_gram_kernel<TAPS>, dim3(chunks, a->N), dim3(256), (size_t)a->C_in * span * sizeof(bf16_t), s,
+                           (const bf16_t*)a->audio, gpart, g, span, TCS);
+        hipLaunchKernelGGL(conv0_fold_f64_kernel, dim3(1, a->N), dim3(256), 0, s, (const double*)gpart, chunks, (int)G, gfold);
+        hipLaunchKernelGGL(conv0_stats_from_gram_kernel<TAPS>, dim3((a->C + 255) / 256, a->N), dim3(256), 0, s, (const double*)gfold,
+                           (const bf16_t*)a->w, sums, a->yx, a->x1, g);
+    } else {
+        hipLaunchKernelGGL(conv0_stats_mfma_kernel<TAPS>, dim3(chunks, a->N), dim3(256), (size_t)a->C_in * span * sizeof(bf16_t), s,
+                           (const bf16_t*)a->audio, (const bf16_t*)a->w, part, want_yx, g, span, TCS);
+        hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
+                           sums, 2L * a->C, a->yx, (long)a->C * TAPS, a->x1, (const int32_t*)nullptr, 1);
+    }
     static const int use_mfma = [] { const char* e = getenv("WJ_CONV0_APPLY_MFMA"); return e ? atoi(e) : 1; }();   // 0: the VALU form (A/B runs)
     if (use_mfma && a->C % 64 == 0 && TAPS <= 32) {
         const int span_a = (TCA - 1) * a->stride + a->k;
