@@ -112,6 +112,18 @@ _STAGING = _PinnedStaging()
 _PINNED_UPLOADS = __import__("os").environ.get("WJ_PINNED_UPLOAD", "1") != "0"     # 0: pageable staging (A/B runs)
 
 
+_UPLOAD_STREAM = __import__("os").environ.get("WJ_UPLOAD_STREAM", "1") != "0"       # 0: uploads on the compute stream (A/B runs)
+_UPLOAD_STREAMS: dict = {}
+
+
+def _upload_stream(device):
+    d = torch.device(device)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    if key not in _UPLOAD_STREAMS:
+        _UPLOAD_STREAMS[key] = torch.cuda.Stream(device=d)
+    return _UPLOAD_STREAMS[key]
+
+
 def pack_upload(arrays: Sequence[np.ndarray], device) -> List[torch.Tensor]:
     """One host -> device copy for a set of small index / mask arrays (uint8 / int32): packed into one byte buffer at 256-byte offsets,
     copied once (from page-locked staging memory when the target is a GPU), returned as typed views of the device buffer (every view
@@ -130,7 +142,19 @@ def pack_upload(arrays: Sequence[np.ndarray], device) -> List[torch.Tensor]:
         host = np.zeros(total, dtype=np.uint8)
     for a, o in zip(arrays, offs):
         host[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-    if on_gpu:
+    if on_gpu and _UPLOAD_STREAM:
+        # On a stream of its own: queued on the compute stream the copy starts only when that stream gets there, and the kernel behind it
+        # waits out the copy engine's latency (~70 us of idle GPU in front of every step's conv0 launches, tools/trace_gaps.py).  The host
+        # runs tens of milliseconds ahead of the GPU, so on its own stream the copy is long done when the compute stream reaches the wait.
+        main = torch.cuda.current_stream(device)
+        up = _upload_stream(device)
+        with torch.cuda.stream(up):
+            dev_buf = slot[0][:total].to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(up)
+        main.wait_event(slot[1])
+        dev_buf.record_stream(main)
+    elif on_gpu:
         dev_buf = slot[0][:total].to(device, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record(torch.cuda.current_stream(device))
