@@ -332,6 +332,7 @@ class JepaEngine:
         # backward) runs beside the main chain and fills the tails / write bursts of its kernels (WJ_SIDE_STREAM=0: off)
         import os as _os
         self.use_side = _os.environ.get("WJ_SIDE_STREAM", "1") != "0"
+        self._opt_ev = None
         # visible-token (ragged) execution of the student and the predictor; WJ_RAGGED=0 keeps the reference's dense
         # key-masked shapes (identical loss and gradients, ~2x the work)
         self.ragged = _os.environ.get("WJ_RAGGED", "1") != "0"
@@ -516,6 +517,8 @@ class JepaEngine:
     def prepare_weights(self, force_cast: bool = False) -> None:
         """bf16 shadow copies (when stale) + the GEMM layouts of conv layers 1.. from the fp32 masters."""
         f = self.flat
+        if force_cast or not f.bf16_fresh or self.fp8:
+            self.wait_optimizer()
         for mine, src in zip((self.pos_enc, self.pos_dec), self._pos_src):
             if mine.data_ptr() != src.data_ptr():
                 mine.copy_(src.reshape(mine.shape))
@@ -877,6 +880,20 @@ class JepaEngine:
         with torch.cuda.stream(self.side):
             fn()
 
+    def optimizer_on_side(self, fn) -> None:
+        """The parameter update of everything the front-end does not read, on the side stream behind everything the compute stream has
+        queued (gradient norm, the front-end parameters' update); the compute stream waits for it in wait_optimizer()."""
+        self._on_side(fn)
+        self._opt_ev = torch.cuda.Event()
+        self._opt_ev.record(self.side)
+
+    def wait_optimizer(self) -> None:
+        """The compute stream waits for a parameter update still in flight on the side stream (no host wait).  Called by the forward in front
+        of its first transformer kernel, by inference, the EMA, weight preparation and state_dict."""
+        if self._opt_ev is not None:
+            torch.cuda.current_stream().wait_event(self._opt_ev)
+            self._opt_ev = None
+
     def _join_side(self) -> None:
         if self.use_side:
             ev = torch.cuda.Event()
@@ -1012,6 +1029,7 @@ class JepaEngine:
             if torch.is_grad_enabled():
                 self.refresh_wt()       # W^T shadows for the backward's row-form dgrads: off the forward's critical path
         self._on_side(beside)
+        self.wait_optimizer()           # (an update overlapped with this step's front-end: the transformer stacks' parameters)
         self.ragged_step = self.ragged and plan.ragged_ok
         if self.ragged_step and self.sparse_conv and torch.is_grad_enabled():
             # host-side list building + upload, hidden behind the forward kernels already queued.  (Building the lists later, behind
@@ -1391,6 +1409,7 @@ class JepaEngine:
     # ------------------------------------------------------------------------------------------------ EMA / inference
     def ema_step(self, r: float) -> None:
         f = self.flat
+        self.wait_optimizer()
         ops.ema_update(f.p32.data_ptr() + 4 * f.enc_offset, f.t32, f.enc_numel, r, teacher_bf16=f.t16)
 
     def infer(self, audio: torch.Tensor, key_mask_u8: Optional[torch.Tensor]) -> torch.Tensor:
@@ -1399,6 +1418,7 @@ class JepaEngine:
         N = audio.shape[0]
         if N != self.N:
             self.alloc(N, train=False)
+        self.wait_optimizer()
         self._frontend(audio)
         a = self.scratch
         x, xb = self.lf, self.lf_b

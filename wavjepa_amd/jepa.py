@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -119,6 +120,9 @@ class _EngineLoss(torch.autograd.Function):
         return torch.zeros_like(m._anchor), None
 
 
+_ADAMW_SIDE = os.environ.get("WJ_ADAMW_SIDE", "1") != "0"
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (reference jepa.py:215-222) as ONE kernel over the flat parameter buffer, with the
     global-norm clip of Lightning's gradient_clip_val (train.py:177-178) fused in (`max_grad_norm`)."""
@@ -132,6 +136,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._t = 0
         self._sumsq = None
         self._ws = None
+        # overlap_next_forward (set by the training loop, trainer.StepRunner; WJ_ADAMW_SIDE=0 keeps it off): only the conv extractor, the
+        # feature norm and the post-extraction mapper are updated on the compute stream; the transformer stacks (99 % of the parameters,
+        # ~0.65 ms of streaming) go to the engine's side stream, where they run beside the NEXT step's crop / conv0 / conv stack -- matrix-
+        # and VALU-bound kernels that leave the HBM idle, on a side stream that has nothing to do until the conv features exist.  The
+        # engine's forward waits for the event before its first transformer kernel (JepaEngine.wait_optimizer); so do state_dict, the EMA
+        # and inference.  Off by default: a caller that reads parameters right behind step() on its own stream would race the update.
+        self.overlap_next_forward = False
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -150,9 +161,20 @@ class FusedAdamW(torch.optim.Optimizer):
         self._t += 1
         if self.max_grad_norm > 0:
             ops.grad_sumsq(flat.g32, self._sumsq, self._ws, flat.n)
-        ops.adamw_step(flat.p32, flat.g32, flat.adam_m, flat.adam_v, flat.n, lr=float(g["lr"]), beta1=g["betas"][0],
-                       beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._t,
-                       max_norm=self.max_grad_norm, sumsq=self._sumsq if self.max_grad_norm > 0 else None, p_bf16=flat.p16)
+        kw = dict(lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._t,
+                  max_norm=self.max_grad_norm, sumsq=self._sumsq if self.max_grad_norm > 0 else None)
+
+        def update(lo: int, hi: int) -> None:
+            ops.adamw_step(flat.p32.data_ptr() + 4 * lo, flat.g32.data_ptr() + 4 * lo, flat.adam_m.data_ptr() + 4 * lo,
+                           flat.adam_v.data_ptr() + 4 * lo, hi - lo, p_bf16=flat.p16.data_ptr() + 2 * lo, **kw)
+        eng = m._engine
+        front, rest = flat.front_and_rest_ranges()
+        if self.overlap_next_forward and eng.use_side and rest and _ADAMW_SIDE:
+            for lo, hi in front:
+                update(lo, hi)
+            eng.optimizer_on_side(lambda: [update(lo, hi) for lo, hi in rest])
+        else:
+            update(0, flat.n)
         m._student_bf16_fresh = True
         return loss
 
@@ -165,6 +187,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         flat = self._module._flat
+        if self._module._engine is not None:
+            self._module._engine.wait_optimizer()
         return dict(step=self._t, lr=self.param_groups[0]["lr"], m=None if flat is None or flat.adam_m is None else flat.adam_m.cpu(),
                     v=None if flat is None or flat.adam_v is None else flat.adam_v.cpu())
 
@@ -172,7 +196,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._t = int(sd["step"])
         if sd.get("lr") is not None:     # LambdaLR.load_state_dict does not write the group lr back: without this the first
             self.param_groups[0]["lr"] = float(sd["lr"])   # resumed step would run at the constructor's lr
-        self._module._ensure_engine()
+        self._module._ensure_engine().wait_optimizer()
         flat = self._module._flat
         flat.ensure_adam_state()
         if sd.get("m") is not None:
@@ -332,7 +356,14 @@ class JEPA(_ModuleBase):
         self._engine = None
         return out
 
+    def state_dict(self, *args, **kw):
+        if getattr(self, "_engine", None) is not None:
+            self._engine.wait_optimizer()     # an update overlapped with the next forward (FusedAdamW.overlap_next_forward) writes these tensors
+        return super().state_dict(*args, **kw)
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        if getattr(self, "_engine", None) is not None:
+            self._engine.wait_optimizer()
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._student_bf16_fresh = False
         self._teacher_bf16_fresh = False

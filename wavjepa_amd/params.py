@@ -78,6 +78,23 @@ class FlatParams:
         self.bf16_fresh = False
 
     # -- pointers -----------------------------------------------------------------------------------------------
+    def front_and_rest_ranges(self):
+        """[lo, hi) element ranges of the flat buffers: `front` = what the forward needs before its first transformer kernel (mask token, conv
+        extractor, feature norm, post-extraction mapper), `rest` = the transformer stacks and their mappers; both padded to the 8-element
+        slot granularity, together exactly [0, n)."""
+        if getattr(self, "_fr", None) is None:
+            is_front = lambda nm: nm.startswith(("mask_token", "extract_audio.", "feature_norms.", "post_extraction_mapper."))
+            runs = []
+            for sl in sorted(self.slots, key=lambda t: t.offset):
+                lo, hi, f = sl.offset, sl.offset + (sl.numel + 7) // 8 * 8, is_front(sl.name)
+                if runs and runs[-1][2] == f and runs[-1][1] == lo:
+                    runs[-1][1] = hi
+                else:
+                    runs.append([lo, hi, f])
+            assert runs and runs[0][0] == 0 and runs[-1][1] == self.n and all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+            self._fr = ([(lo, hi) for lo, hi, f in runs if f], [(lo, hi) for lo, hi, f in runs if not f])
+        return self._fr
+
     def ptr32(self, name: str) -> int:
         return self.p32.data_ptr() + 4 * self.by_name[name].offset
 

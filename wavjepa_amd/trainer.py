@@ -95,6 +95,9 @@ class StepRunner:
         self.optimizer = oc["optimizer"]
         self.scheduler = oc["lr_scheduler"]["scheduler"]
         self.optimizer.max_grad_norm = float(gradient_clip_val or 0.0)
+        if self.sectioned and hasattr(self.optimizer, "overlap_next_forward"):
+            # (JEPA only: its engine's forward knows where to wait.)  This loop reads parameters only through the engine / state_dict, which wait
+            self.optimizer.overlap_next_forward = True
 
     def step(self, raw_batch, batch_idx: int) -> Dict[str, Any]:
         m = self.model
