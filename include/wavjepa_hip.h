@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 14
+#define WJ_ABI_VERSION 15
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -562,6 +562,9 @@ typedef struct {
     const float* sumsq;
     int64_t n;
     float lr, beta1, beta2, eps, weight_decay, bc1, bc2, max_norm, grad_scale;
+    int32_t workgroups; /* ABI 15.  0: as many as the range fills (<= 8192).  > 0: at most this many (the kernel strides): an update that runs
+                         * beside MFMA- / VALU-bound kernels of another stream (the training loop's overlapped update) should take the
+                         * idle HBM, not the other kernels' CU slots */
 } wj_adamw_args;
 int wj_adamw_step(const wj_adamw_args*, void* stream);
 

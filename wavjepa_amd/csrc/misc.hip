@@ -850,7 +850,9 @@ extern "C" int wj_grad_sumsq(const wj_sumsq_args* a, void* stream) {
 extern "C" int wj_adamw_step(const wj_adamw_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n / 4, 256)), dim3(256), 0, STREAM, *a);
+    int grid = grid_for(a->n / 4, 256);
+    if (a->workgroups > 0 && a->workgroups < grid) grid = a->workgroups;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, STREAM, *a);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

@@ -121,6 +121,9 @@ class _EngineLoss(torch.autograd.Function):
 
 
 _ADAMW_SIDE = os.environ.get("WJ_ADAMW_SIDE", "1") != "0"
+# workgroups of the overlapped update: one per CU -- it should take the HBM the front-end kernels leave idle, not their CU slots
+# (a full grid of 8192: 45.68 ms/step, 1024: 45.64, 512: 45.48, 256: 45.40, interleaved on one box; 128 / 192 / 384 within 0.1 of 256)
+_ADAMW_SIDE_WGS = int(os.environ.get("WJ_ADAMW_SIDE_WGS", "256"))
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -164,15 +167,15 @@ class FusedAdamW(torch.optim.Optimizer):
         kw = dict(lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._t,
                   max_norm=self.max_grad_norm, sumsq=self._sumsq if self.max_grad_norm > 0 else None)
 
-        def update(lo: int, hi: int) -> None:
+        def update(lo: int, hi: int, workgroups: int = 0) -> None:
             ops.adamw_step(flat.p32.data_ptr() + 4 * lo, flat.g32.data_ptr() + 4 * lo, flat.adam_m.data_ptr() + 4 * lo,
-                           flat.adam_v.data_ptr() + 4 * lo, hi - lo, p_bf16=flat.p16.data_ptr() + 2 * lo, **kw)
+                           flat.adam_v.data_ptr() + 4 * lo, hi - lo, p_bf16=flat.p16.data_ptr() + 2 * lo, workgroups=workgroups, **kw)
         eng = m._engine
         front, rest = flat.front_and_rest_ranges()
         if self.overlap_next_forward and eng.use_side and rest and _ADAMW_SIDE:
             for lo, hi in front:
                 update(lo, hi)
-            eng.optimizer_on_side(lambda: [update(lo, hi) for lo, hi in rest])
+            eng.optimizer_on_side(lambda: [update(lo, hi, _ADAMW_SIDE_WGS) for lo, hi in rest])
         else:
             update(0, flat.n)
         m._student_bf16_fresh = True

@@ -418,8 +418,8 @@ def grad_sumsq(g: Ptr, out: Ptr, workspace: Ptr, n: int, stream: Optional[int] =
 
 def adamw_step(p: Ptr, g: Ptr, m: Ptr, v: Ptr, n: int, *, lr: float, beta1: float, beta2: float, eps: float,
                weight_decay: float, step: int, max_norm: float = 0.0, sumsq: Ptr = None, p_bf16: Ptr = None,
-               grad_scale: float = 1.0, stream: Optional[int] = None) -> None:
-    _run("wj_adamw_step", "wj_adamw_args", stream, p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p_bf16), sumsq=_p(sumsq),
+               grad_scale: float = 1.0, workgroups: int = 0, stream: Optional[int] = None) -> None:
+    _run("wj_adamw_step", "wj_adamw_args", stream, workgroups=int(workgroups), p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p_bf16), sumsq=_p(sumsq),
          n=n, lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, bc1=1.0 - beta1 ** step,
          bc2=1.0 - beta2 ** step, max_norm=max_norm, grad_scale=grad_scale)
 
