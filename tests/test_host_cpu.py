@@ -217,6 +217,17 @@ def test_flat_params_and_gradient_bucket_tiling():
     assert total == flat.n
     # student-encoder slice mirrors the teacher buffer (single-kernel EMA)
     assert flat.enc_numel == flat.tn
+    # the optimiser's split (FusedAdamW.overlap_next_forward): what the front-end reads before the first transformer kernel / the rest;
+    # together exactly [0, n), the encoder slice (what the EMA reads) entirely in `rest`
+    front, rest = flat.front_and_rest_ranges()
+    runs = sorted(front + rest)
+    assert runs[0][0] == 0 and runs[-1][1] == flat.n and all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+    assert all(lo % 8 == 0 and hi % 8 == 0 for lo, hi in runs)
+    inside = lambda off, rs: any(lo <= off < hi for lo, hi in rs)
+    for sl in flat.slots:
+        is_front = sl.name.startswith(("mask_token", "extract_audio.", "feature_norms.", "post_extraction_mapper."))
+        assert inside(sl.offset, front) == is_front and inside(sl.offset, rest) == (not is_front), sl.name
+    assert inside(flat.enc_offset, rest) and inside(flat.enc_offset + flat.enc_numel - 1, rest)
 
 
 def test_workspace_query():
