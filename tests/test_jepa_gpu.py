@@ -1029,3 +1029,38 @@ def test_state_dict_roundtrip_and_reference_checkpoint_layout():
     m2.load_state_dict(sd)
     for k, v in m2.state_dict().items():
         assert torch.equal(v.cpu(), sd[k]), k
+
+
+def test_overlapped_adamw_is_the_same_update(golden_dir):
+    """The training loop's optimiser split (FusedAdamW.overlap_next_forward: the transformer stacks' update on the side stream beside the
+    next step's conv front-end, one workgroup per CU; the forward / state_dict wait for its event) against the single launch on the compute
+    stream: the same trajectory -- parameters, teacher, Adam moments, loss -- up to the run-to-run noise of the fp32 split-K atomics in the
+    weight gradients.  A missing wait shows as a stale or half-written parameter buffer, orders of magnitude above that noise."""
+    from wavjepa_amd.trainer import StepRunner
+    ctx, tgt, vis = masks(golden_dir, 4)
+    runs = []
+    for overlap in (False, True):
+        m, _ = build(SMALL, warmup_steps=2)
+        m.trainer.max_steps = 20
+        run = StepRunner(m)
+        assert run.optimizer.overlap_next_forward               # the loop switches it on for JEPA
+        run.optimizer.overlap_next_forward = overlap
+        for i in range(5):
+            audio = torch.from_numpy(synth.synth_audio(4, 1, 32159, seed=500 + i)).to(torch.bfloat16).to(dev())
+            out = m.training_step((audio, ctx, tgt, vis), i)
+            out["loss"].backward()
+            run.reducer.wait()
+            run.optimizer.step()
+            run.scheduler.step()
+            m.global_step = i + 1
+        assert (m._engine._opt_ev is not None) == overlap        # an update is still in flight behind the last step
+        sd = {k: v.detach().float().clone() for k, v in m.state_dict().items()}    # (state_dict waits for it)
+        assert m._engine._opt_ev is None
+        osd = run.optimizer.state_dict()
+        torch.cuda.synchronize()
+        runs.append((sd, osd["m"].float(), osd["v"].float(), float(out["loss"].detach())))
+    (sd0, m0, v0, l0), (sd1, m1, v1, l1) = runs
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
+    for k in sd0:
+        assert rel(sd1[k], sd0[k]) < 2e-5, (k, rel(sd1[k], sd0[k]))
+    assert rel(m1, m0) < 1e-4 and rel(v1, v0) < 1e-4
