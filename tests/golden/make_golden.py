@@ -21,6 +21,8 @@ Fixtures written:
   misc.npz            sin-cos tables slices/checksums, EMA decay schedule, LR schedule samples.
   channel_frontend.npz  ConvChannelFeatureExtractor (own / shared stacks) weights + input + output, get_binaural_pos_embed
                       slices, channel-based masks under a pinned numpy Generator sequence.
+  large_forward.npz   (python tests/golden/make_golden.py large) the reference's size="large" model (student d=1024 x 24, 16 heads), synthesised
+                      weights, N=2: state_dict layout, fp32 loss, slices, per-group gradient norms.
   base_traj.npz       (python tests/golden/make_golden.py base_traj) 100 optimisation steps of the BASE model, N=4, through
                       the reference's training_step / EMA / clip / AdamW / schedule, fp32 and bf16-autocast: per-step loss,
                       grad norm, lr, EMA decay, final parameter checksums and slices (the north-star trajectory).
@@ -293,6 +295,53 @@ def gen_base(masks):
     fx["n_params_trainable"] = sum(p.numel() for p in m.parameters() if p.requires_grad)
     fx["seconds"] = time.time() - t0
     np.savez_compressed(os.path.join(HERE, "base_forward.npz"), **fx)
+    return m
+
+
+def gen_large(masks):
+    """The reference's `size="large"` branch (jepa.py:114-118): ViT-Large student (d = 1024, 16 heads, 24 layers, feed-forward 4096) built from the
+    BASE layer configs exactly as train.py would with trainer.size=large; predictor unchanged (d = 384 x 12).  Hash-synthesised weights, N = 2,
+    fp32 forward + backward on the CPU: names / shapes of the state_dict, loss, tensor slices, per-group gradient norms."""
+    t0 = time.time()
+    torch.manual_seed(0)
+    m = build_ref(BASE_SPEC, 768, 12, 12, 384, 12, 12, top_k=8, size="large")
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref_shapes = synth.jepa_shapes(conv_spec=BASE_SPEC, in_channels=1, d_enc=1024, enc_layers=24, d_dec=384, dec_layers=12, n_tokens=200)
+    assert shapes == ref_shapes, "synth.jepa_shapes (large) differs from the reference state_dict"
+    assert m.n_encoder_heads == 16 and m.encoder_embedding_dim == 1024 and len(m.encoder.layers) == 24
+    sd = synth.synth_state_dict(shapes, seed=11)
+    for k in list(sd):
+        if k.startswith("teacher_encoder.") and k.endswith("weight") and sd[k].ndim == 2:
+            sd[k] = (sd[k] * np.float32(0.97)).astype(np.float32)
+    own = m.state_dict()
+    for k, v in sd.items():
+        own[k].copy_(torch.from_numpy(v))
+    N = 2
+    audio = torch.from_numpy(synth.synth_audio(N, 1, 32159, seed=5))
+    ctx, tgt, vis = (torch.from_numpy(masks[k][:N]) for k in ("as_ctx", "as_tgt", "as_vis"))
+    m.train()
+    out = m(audio, ctx, tgt, vis)
+    out["loss"].backward()
+    fx = dict(loss=out["loss"].detach().numpy(), n=N, weight_seed=11, audio_seed=5, teacher_scale=0.97, n_tensors=len(shapes),
+              enc_heads=m.n_encoder_heads, d_enc=m.encoder_embedding_dim, enc_layers=len(m.encoder.layers))
+    fx["local_features_slice"] = out["local_features"][:, ::25, ::64].detach().numpy()
+    fx["contextual_features_slice"] = out["contextual_features"][::7, ::16].detach().numpy()
+    fx["preds_slice"] = out["preds"][:, ::25, ::64].detach().numpy()
+    fx["targets_slice"] = out["targets"][:, ::25, ::64].detach().numpy()
+    groups = {"conv": "extract_audio.", "feature_norms": "feature_norms.", "mapper": "post_extraction_mapper.",
+              "encoder": "encoder.", "enc2dec": "encoder_to_decoder_mapper.", "decoder": "decoder.",
+              "dec2enc": "decoder_to_encoder_mapper.", "mask_token": "mask_token"}
+    gn = {}
+    for g, pre in groups.items():
+        gn[g] = sum(float(p.grad.double().pow(2).sum()) for n, p in m.named_parameters() if n.startswith(pre) and p.grad is not None) ** 0.5
+    fx["grad_group_names"] = np.array(list(gn.keys()))
+    fx["grad_group_norms"] = np.array(list(gn.values()))
+    fx["grad_slice::encoder.layers.23.linear1.weight"] = m.encoder.layers[23].linear1.weight.grad[::256, ::64].numpy()
+    fx["grad_slice::encoder.layers.0.self_attn.in_proj_weight"] = m.encoder.layers[0].self_attn.in_proj_weight.grad[::192, ::64].numpy()
+    fx["n_params_total"] = sum(v.numel() for v in m.state_dict().values())
+    fx["n_params_trainable"] = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    fx["seconds"] = time.time() - t0
+    np.savez_compressed(os.path.join(HERE, "large_forward.npz"), **fx)
     return m
 
 
@@ -734,6 +783,8 @@ if __name__ == "__main__":
         gen_signatures()
     if "hear_runtime" in which:       # ~1 min of CPU (base model, 2 windows x 2 clips): not part of the default list
         gen_hear_runtime()
+    if "large" in which:              # ~2 min of CPU, 8 GB: not part of the default list
+        gen_large(masks)
     if "base_traj" in which:          # ~15 min of CPU: not part of the default list
         gen_base_traj(masks)
     for f in sorted(os.listdir(HERE)):

@@ -175,6 +175,28 @@ def test_train_py_config1_tiny_model_batch_of_four(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_train_py_size_large_three_steps(tmp_path):
+    """`train.py trainer.size=large` (reference jepa.py:114-118): the ViT-Large student (d = 1024, 16 x 64 heads, 24 layers, feed-forward
+    4096) through the launcher for three optimisation steps -- GEMM K = 1024 / 4096, LayerNorm D = 1024, the 24-layer arena, flat-parameter
+    layout and checkpoint.  Finite, the loss moves, the checkpoint carries the large layout."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train.py"), "trainer.size=large", "trainer.batch_size=2", "data.samples_per_audio=4",
+           "trainer.steps=3", "trainer.warmup_steps=1", "trainer.log_every_n_steps=1", f"save_dir={tmp_path / 'runs'}"]
+    from tests import launch
+    rc, out, err = launch.run(cmd, cwd=root, timeout=600)
+    assert rc == 0, (out[-1500:], err[-4000:])
+    losses = [float(ln.split("loss")[1].split()[0]) for ln in out.splitlines() if ln.startswith("step ")]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] != losses[0], out[-1500:]
+    import torch
+    sd = torch.load(next((tmp_path / "runs").rglob("last.ckpt")), map_location="cpu", weights_only=False)["state_dict"]
+    assert sd["encoder.layers.23.linear1.weight"].shape == (4096, 1024) and "encoder.layers.24.linear1.weight" not in sd
+    assert sd["teacher_encoder.layers.23.self_attn.in_proj_weight"].shape == (3072, 1024)
+    assert sd["decoder.layers.11.linear1.weight"].shape == (1536, 384) and sd["post_extraction_mapper.weight"].shape == (1024, 512)
+    assert sd["pos_encoding_encoder"].shape == (1, 200, 1024) and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+
+
+@pytest.mark.timeout(900)
 def test_train_py_config4_nat_scenes_two_ranks_over_gloo(tmp_path):
     """BASELINE config 4 through the launcher: `train.py extractor=wavjepa_nat data=nat_synthetic masker=AudioSet_nat` under
     torch.distributed.run with two ranks -- binaural scenes generated on the device inside the step (source RIR + 2 noise RIRs, SNR

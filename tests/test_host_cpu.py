@@ -230,6 +230,40 @@ def test_flat_params_and_gradient_bucket_tiling():
     assert inside(flat.enc_offset, rest) and inside(flat.enc_offset + flat.enc_numel - 1, rest)
 
 
+def test_size_large_layout_and_gradient_buckets_at_24_layers(golden_dir):
+    """size="large" (reference jepa.py:114-118): the constructor is handed the BASE layer configs and widens the student to ViT-Large.  Built on
+    the meta device (600 M parameters: no storage needed for a layout check): state_dict names / shapes against the reference's own large model
+    (tests/golden/large_forward.npz, written by make_golden.py `large`), the flat-parameter layout, and the all-reduce buckets of
+    ddp.section_ranges tiling the flat gradient buffer at 24 encoder layers (8 chunks of 3)."""
+    import types
+    from wavjepa_amd.ddp import section_ranges
+    from wavjepa_amd.extractors import ConvFeatureExtractor
+    from wavjepa_amd.jepa import JEPA
+    from wavjepa_amd.params import _layout
+    from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    with torch.device("meta"):
+        ext = ConvFeatureExtractor(conv_layers_spec=SPEC, in_channels=1)
+        m = JEPA(feature_extractor=ext, transformer_encoder_cfg=TransformerEncoderCFG.create(), transformer_encoder_layers_cfg=TransformerLayerCFG.create(),
+                 transformer_decoder_cfg=TransformerEncoderCFG.create(), transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=384),
+                 average_top_k_layers=8, process_audio_seconds=2.01, nr_samples_per_audio=8, size="large")
+    assert (m.encoder_embedding_dim, m.n_encoder_heads, m.encoder.num_layers, m.decoder_embedding_dim, m.decoder.num_layers) == (1024, 16, 24, 384, 12)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert shapes == synth.jepa_shapes(conv_spec=SPEC, in_channels=1, d_enc=1024, enc_layers=24, d_dec=384, dec_layers=12, n_tokens=200)
+    fx = np.load(os.path.join(golden_dir, "large_forward.npz"))
+    assert len(shapes) == int(fx["n_tensors"]) and sum(int(np.prod(s)) for s in shapes.values()) == int(fx["n_params_total"])
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == int(fx["n_params_trainable"])
+    slots, n = _layout([(k, p) for k, p in m.named_parameters() if p.requires_grad])
+    flat = types.SimpleNamespace(slots=slots, n=n)
+    ranges = section_ranges(flat, enc_layers=24, enc_chunk=3)
+    assert set(ranges) == {"dec", "front"} | {f"enc:{i}" for i in range(0, 24, 3)}
+    assert sum(hi - lo for v in ranges.values() for lo, hi in v) == n
+    by = {s.name: s for s in slots}
+    lo, hi = ranges["enc:21"][0]            # the top chunk carries layers 21-23 and the final norm
+    for name in ("encoder.layers.21.linear1.weight", "encoder.layers.23.linear2.bias", "encoder.norm.weight"):
+        assert lo <= by[name].offset < hi, name
+    assert not lo <= by["encoder.layers.20.linear2.bias"].offset < hi
+
+
 def test_workspace_query():
     """wj_workspace_bytes: the caller sizes every scratch buffer from the library (no compute, runs without a GPU)."""
     from wavjepa_amd import ops

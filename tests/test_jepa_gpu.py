@@ -19,6 +19,8 @@ SMALL_SPEC = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)]
 SMALL = dict(conv_spec=SMALL_SPEC, d_enc=128, h_enc=2, l_enc=2, d_dec=64, h_dec=2, l_dec=2, top_k=2)
 SMALL16 = dict(SMALL, h_enc=4, h_dec=4)      # BASELINE config 1's head layout: student 4 x 32, predictor 4 x 16
 BASE = dict(conv_spec=list(J.WAVJEPA_CONV_SPEC), d_enc=768, h_enc=12, l_enc=12, d_dec=384, h_dec=12, l_dec=12, top_k=8)
+# the reference's size="large" branch (jepa.py:114-118): the constructor gets the BASE layer configs and overrides the student to ViT-Large
+LARGE = dict(BASE, d_enc=1024, h_enc=16, l_enc=24)
 
 
 def dev():
@@ -35,14 +37,17 @@ def build(cfg, seed=7, teacher_scale=0.97, seconds=2.01, tokens=200, in_channels
     from wavjepa_amd.extractors import ConvChannelFeatureExtractor, ConvFeatureExtractor
     from wavjepa_amd.jepa import JEPA
     from wavjepa_amd.types import TransformerEncoderCFG, TransformerLayerCFG
+    ctor = cfg
+    if kw.get("size") == "large":       # as train.py builds it: base layer configs in, the size switch widens the student
+        ctor = dict(cfg, d_enc=768, h_enc=12, l_enc=12)
     if channel_stacks is None:
         ext = ConvFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=in_channels)
     else:   # "own" / "shared": every channel through a mono stack (WavJEPA-Nat, BASELINE config 4)
         ext = ConvChannelFeatureExtractor(conv_layers_spec=cfg["conv_spec"], in_channels=in_channels,
                                           share_weights_over_channels=channel_stacks == "shared")
     m = JEPA(feature_extractor=ext,
-             transformer_encoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_enc"]),
-             transformer_encoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_enc"], nhead=cfg["h_enc"]),
+             transformer_encoder_cfg=TransformerEncoderCFG.create(num_layers=ctor["l_enc"]),
+             transformer_encoder_layers_cfg=TransformerLayerCFG.create(d_model=ctor["d_enc"], nhead=ctor["h_enc"]),
              transformer_decoder_cfg=TransformerEncoderCFG.create(num_layers=cfg["l_dec"]),
              transformer_decoder_layers_cfg=TransformerLayerCFG.create(d_model=cfg["d_dec"], nhead=cfg["h_dec"]),
              lr=4e-4, adam_betas=(0.9, 0.98), adam_weight_decay=0.04, average_top_k_layers=cfg["top_k"],
@@ -117,13 +122,15 @@ def group_of(name):
 ACT_TOL = {"base": dict(local_features=8.6e-3, targets=8.6e-3, contextual_features=8.6e-3, preds=7.0e-3),
            "small": dict(local_features=9.2e-3, targets=9.6e-3, contextual_features=1.08e-2, preds=7.5e-3)}
 ACT_TOL["small16"] = ACT_TOL["small"]
-GRAD_TOL = {"base": 1.0e-2, "small": 1.5e-2, "small16": 1.5e-2}
+ACT_TOL["large"] = ACT_TOL["base"]
+GRAD_TOL = {"base": 1.0e-2, "small": 1.5e-2, "small16": 1.5e-2, "large": 1.0e-2}
 
 
 @pytest.mark.parametrize("cfg_name,n,ragged", [("small", 4, True), ("small", 4, False), ("small", 1, True), ("small", 1, False),
                                                 ("small16", 4, True), ("small16", 4, False),  # 16-wide predictor heads (config 1)
                                                 ("base", 2, True), ("base", 2, False),       # n = 1: a single clip (fewer rows than one GEMM tile)
-                                                ("base", 64, True)])
+                                                ("base", 64, True),
+                                                ("large", 2, True), ("large", 2, False)])    # size="large": d = 1024, 16 x 64 heads, 24 layers
 def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     """ragged = visible-token execution (the default); dense = the reference's key-masked full-length shapes.  Both must
     give the oracle's loss, outputs and gradients.
@@ -131,8 +138,10 @@ def test_forward_backward_parity(golden_dir, cfg_name, n, ragged):
     persistent eight-phase GEMM: in_proj, linear1 + GELU, out_proj / linear2 stay on the one-tile schedules), predictor
     M ~ 21 600 (persistent in_proj / linear1 / MUL_GELU_GRAD, half-width N = 384 items), grouped weight gradients at their real
     split factors, ragged arena sized from the row counts -- end to end against the oracle, not only op by op."""
-    cfg = {"small": SMALL, "small16": SMALL16, "base": BASE}[cfg_name]
-    m, P = build(cfg)
+    cfg = {"small": SMALL, "small16": SMALL16, "base": BASE, "large": LARGE}[cfg_name]
+    m, P = build(cfg, **(dict(size="large") if cfg_name == "large" else {}))
+    if cfg_name == "large":
+        assert (m.encoder_embedding_dim, m.n_encoder_heads, m.encoder.num_layers) == (1024, 16, 24)
     m._ensure_engine().ragged = ragged
     ctx, tgt, vis = masks(golden_dir, n)
     audio = torch.from_numpy(synth.synth_audio(n, 1, 32159, seed=3)).to(torch.bfloat16).to(dev())

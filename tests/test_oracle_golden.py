@@ -211,6 +211,47 @@ def test_base_forward_backward(golden_dir):
     assert rel(P["encoder.layers.0.linear1.weight"].grad[::128, ::64], fx["grad_slice::encoder.layers.0.linear1.weight"]) < 1e-3
 
 
+def test_large_forward_backward(golden_dir):
+    """The reference's size="large" model (jepa.py:114-118: student d = 1024, 16 heads, 24 layers; tests/golden/large_forward.npz) with
+    hash-synthesised weights, N = 2: the oracle's fp32 flow against the reference's loss, output slices and per-group gradient norms."""
+    fx = load(golden_dir, "large_forward.npz")
+    masks = load(golden_dir, "masks.npz")
+    assert (int(fx["d_enc"]), int(fx["enc_heads"]), int(fx["enc_layers"])) == (1024, 16, 24)
+    shapes = synth.jepa_shapes(conv_spec=J.WAVJEPA_CONV_SPEC, in_channels=1, d_enc=1024, enc_layers=24, d_dec=384, dec_layers=12, n_tokens=200)
+    assert len(shapes) == int(fx["n_tensors"])
+    sd = synth.synth_state_dict(shapes, seed=int(fx["weight_seed"]))
+    for k in list(sd):
+        if k.startswith("teacher_encoder.") and k.endswith("weight") and sd[k].ndim == 2:
+            sd[k] = (sd[k] * np.float32(float(fx["teacher_scale"]))).astype(np.float32)
+    P = {k: torch.from_numpy(v) for k, v in sd.items()}
+    P["pos_encoding_encoder"] = J.sincos_positions(1024, 200)
+    P["pos_encoding_decoder"] = J.sincos_positions(384, 200)
+    assert sum(v.numel() for v in P.values()) == int(fx["n_params_total"])
+    names = J.trainable_names(P)
+    assert sum(P[n].numel() for n in names) == int(fx["n_params_trainable"])
+    for n in names:
+        P[n].requires_grad_(True)
+    N = int(fx["n"])
+    audio = torch.from_numpy(synth.synth_audio(N, 1, 32159, seed=int(fx["audio_seed"])))
+    ctx, tgt, vis = (torch.from_numpy(masks[k][:N]) for k in ("as_ctx", "as_tgt", "as_vis"))
+    out = J.jepa_forward(P, audio, ctx, tgt, vis, mode="fp32", enc_heads=16, dec_heads=12, top_k=8)
+    assert abs(float(out["loss"]) - float(fx["loss"])) < 2e-5 * float(fx["loss"])
+    assert rel(out["local_features"][:, ::25, ::64], fx["local_features_slice"]) < 1e-4
+    assert rel(out["contextual_features"][::7, ::16], fx["contextual_features_slice"]) < 1e-4
+    assert rel(out["preds"][:, ::25, ::64], fx["preds_slice"]) < 1e-4
+    assert rel(out["targets"][:, ::25, ::64], fx["targets_slice"]) < 1e-4
+    out["loss"].backward()
+    groups = {"conv": "extract_audio.", "feature_norms": "feature_norms.", "mapper": "post_extraction_mapper.",
+              "encoder": "encoder.", "enc2dec": "encoder_to_decoder_mapper.", "decoder": "decoder.",
+              "dec2enc": "decoder_to_encoder_mapper.", "mask_token": "mask_token"}
+    want = dict(zip(fx["grad_group_names"].tolist(), fx["grad_group_norms"].tolist()))
+    for g, pre in groups.items():
+        tot = sum(float(P[n].grad.double().pow(2).sum()) for n in names if n.startswith(pre)) ** 0.5
+        assert abs(tot - want[g]) < 1e-3 * want[g], (g, tot, want[g])
+    assert rel(P["encoder.layers.23.linear1.weight"].grad[::256, ::64], fx["grad_slice::encoder.layers.23.linear1.weight"]) < 1e-3
+    assert rel(P["encoder.layers.0.self_attn.in_proj_weight"].grad[::192, ::64], fx["grad_slice::encoder.layers.0.self_attn.in_proj_weight"]) < 1e-3
+
+
 def test_channel_frontend_binaural_positions_and_channel_masks(golden_dir):
     """WavJEPA-Nat front-end pieces against the reference's outputs (tests/golden/channel_frontend.npz): the oracle's
     ConvChannelFeatureExtractor restatement (own and shared stacks, channel-major flatten), get_binaural_pos_embed (oracle AND the

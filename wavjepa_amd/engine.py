@@ -883,16 +883,21 @@ class JepaEngine:
     def optimizer_on_side(self, fn) -> None:
         """The parameter update of everything the front-end does not read, on the side stream behind everything the compute stream has
         queued (gradient norm, the front-end parameters' update); the compute stream waits for it in wait_optimizer()."""
+        self._opt_main = torch.cuda.current_stream()       # the compute stream the update was issued from
         self._on_side(fn)
         self._opt_ev = torch.cuda.Event()
         self._opt_ev.record(self.side)
 
     def wait_optimizer(self) -> None:
-        """The compute stream waits for a parameter update still in flight on the side stream (no host wait).  Called by the forward in front
-        of its first transformer kernel, by inference, the EMA, weight preparation and state_dict."""
+        """The calling stream waits for a parameter update still in flight on the side stream (no host wait).  Called by the forward in front
+        of its first transformer kernel, by inference, the EMA, weight preparation, state_dict, Module._apply and at the end of Trainer.fit.
+        The event is kept until the COMPUTE stream (the one the update was issued from) has waited: a first caller on some other stream
+        (a state_dict inside a `torch.cuda.stream(...)` block) must not consume it for the next forward."""
         if self._opt_ev is not None:
-            torch.cuda.current_stream().wait_event(self._opt_ev)
-            self._opt_ev = None
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._opt_ev)
+            if getattr(self, "_opt_main", None) is None or cur == self._opt_main:
+                self._opt_ev = None
 
     def _join_side(self) -> None:
         if self.use_side:

@@ -145,6 +145,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # and VALU-bound kernels that leave the HBM idle, on a side stream that has nothing to do until the conv features exist.  The
         # engine's forward waits for the event before its first transformer kernel (JepaEngine.wait_optimizer); so do state_dict, the EMA
         # and inference.  Off by default: a caller that reads parameters right behind step() on its own stream would race the update.
+        # With it on, readers that do NOT go through the engine -- a submodule's state_dict (model.encoder.state_dict()), copy.deepcopy,
+        # direct p.data reads -- must call model._engine.wait_optimizer() first; JEPA.state_dict / load_state_dict / _apply (.cpu(), .to())
+        # and Trainer.fit's return do so themselves.
         self.overlap_next_forward = False
 
     @torch.no_grad()
@@ -352,6 +355,10 @@ class JEPA(_ModuleBase):
         return steps if steps > 0 else _NullTrainer.max_steps
 
     def _apply(self, fn, *a, **k):
+        if getattr(self, "_engine", None) is not None:
+            # .cpu() / .to() / .half() read every parameter (and the moments carried below): an update overlapped with the next forward
+            # (FusedAdamW.overlap_next_forward) may still be writing them on the engine's side stream
+            self._engine.wait_optimizer()
         out = super()._apply(fn, *a, **k)
         if self._flat is not None and self._flat.adam_m is not None:
             self._adam_carry = (self._flat.adam_m, self._flat.adam_v, self._flat.n)   # optimiser moments survive .to() / .cuda()
@@ -375,6 +382,8 @@ class JEPA(_ModuleBase):
     def _ensure_engine(self) -> JepaEngine:
         if self._engine is not None and self._flat is not None and self._flat.owns(self):
             return self._engine
+        if self._engine is not None:
+            self._engine.wait_optimizer()      # a rebuilt engine must not drop an update still in flight on the old one's side stream
         ops.require_gpu()
         if self.device.type != "cuda":
             raise RuntimeError("wavjepa_amd.JEPA computes only on an MI355X: move the module with .cuda() first "

@@ -193,6 +193,11 @@ class Trainer:
                 self.save_checkpoint(model, runner, os.path.join(self.root, f"step={gs}.ckpt"), versioned=ckpt_path is None)
         if self.root:
             self.save_checkpoint(model, runner, os.path.join(self.root, "last.ckpt"), versioned=ckpt_path is None)
+        eng = getattr(model, "_engine", None)
+        if eng is not None and hasattr(eng, "wait_optimizer"):
+            # the last step's update of the transformer stacks may still run on the side stream (overlap_next_forward): whatever the caller
+            # does with the model next (export, .cpu(), a submodule's state_dict) is ordered behind it on the compute stream -- no host sync
+            eng.wait_optimizer()
         if self.rank == 0 and self.log_every_n_steps:
             print(f"done: {model.global_step} steps, peak HBM {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB allocated, "
                   f"{torch.cuda.max_memory_reserved(dev) / 2**30:.1f} GiB reserved", flush=True)
