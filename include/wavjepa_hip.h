@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 15
+#define WJ_ABI_VERSION 16
 int wj_abi_version(void);
 /* Number of HIP devices visible (0 on a CPU-only host); never initialises a context beyond hipGetDeviceCount. */
 int wj_device_count(void);
@@ -77,6 +77,15 @@ typedef struct {
                                 problems of 33-128 output tiles and K >= 1536 (the ragged student's N = 768 linears and dgrads: 117 tiles
                                 for 256 CUs) run as K-split PAIRS: two workgroups per tile, half of K each, fp32 partial sums exchanged
                                 through the scratch (csrc/gemm.hip).  NULL / too small: one workgroup per tile, as before. */
+    int32_t schedule;        /* 0: the library picks the tile / schedule variant for the shape (csrc/gemm.hip: pick_variant).  1 + v: force variant
+                                v = 0..4 (4 = the persistent eight-phase kernel); a variant that cannot run the shape falls back to 3, then 0.
+                                Variants 0-3 give bit-identical outputs (same k order, bias added last); variant 4 starts its accumulators
+                                from the bias: a last-place difference of the bf16 output on <= 0.05 % of the elements.  Per call: the
+                                library keeps no selection state (tests and tools/gemm_check.py force each schedule this way). */
+    int32_t persist_cus;     /* resident workgroups per XCD of the persistent schedule, 1..32; 0: the default (32 = one per CU, or the
+                                WJ_PERSIST_CUS environment variable read once at the first launch).  A data-parallel run (train.py:174-179:
+                                DDP over 8 GPUs) passes 28 so that the RCCL channel kernels of the gradient all-reduce find free CUs while a
+                                persistent GEMM of the backward is resident -- a 150-KiB-LDS workgroup on every CU leaves them none. */
 } wj_gemm_args;
 int wj_gemm_bf16(const wj_gemm_args*, void* stream);
 /* ------------------------------------------------------------------------------------------------------------
@@ -129,24 +138,6 @@ typedef struct {
 } wj_wgrad_group_args;
 int wj_wgrad_grouped(const wj_wgrad_group_args*, void* stream);
 
-/* Tuning / A-B hook (tools/gemm_check.py, tests): force the tile/schedule variant of wj_gemm_bf16 (0..4, see csrc/gemm.hip; 4 = the
- * persistent eight-phase kernel of csrc/gemm_persist.hip; a variant that cannot run a shape falls back to 3, then 0); -1 = automatic
- * selection.  Returns the previous setting.  Same effect as the WJ_GEMM_VARIANT environment variable.  Variants 0-3 give bit-identical
- * outputs (same k order, bias added last); variant 4 starts its accumulators from the bias: a last-place difference of the bf16 output
- * on <= 0.05 % of the elements. */
-int wj_gemm_set_variant(int variant);
-
-/* Resident workgroups per XCD of the persistent GEMM (1..32; 32 = one per CU, the default; WJ_PERSIST_CUS sets the initial value).
- * A data-parallel run (train.py:174-179: DDP over 8 GPUs) lowers it so that the RCCL channel kernels of the gradient all-reduce find
- * free CUs while a persistent GEMM of the backward is resident -- a 150-KiB-LDS workgroup on every CU leaves them none.
- * workgroups_per_xcd <= 0 only queries.  Returns the previous value. */
-int wj_gemm_set_persist_cus(int workgroups_per_xcd);
-
-/* Diagnostic (tools/persist_stamps.py; only filled when the process runs with WJ_PERSIST_STAMPS=1): copies the time stamps the last
- * persistent-GEMM launch wrote -- [2][256 workgroups][64] s_memrealtime values (100 MHz): start, end of prologue, per output tile the
- * end of its first K-tile pair / K loop / epilogue; second half: the eight phases of that first pair -- to `out` (n 64-bit words).
- * Synchronises the device.  Not part of the drop-in surface. */
-int wj_debug_persist_stamps(unsigned long long* out, int n);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LayerNorm (fp32 statistics), optionally fused with the post-norm residual add.
@@ -183,6 +174,10 @@ typedef struct {
     int32_t group_rows;
     int32_t in_chan;
     float eps;
+    int32_t workgroups; /* 0: the full grid.  > 0 (no group_stats / y_fp8 / in_seg): at most this many workgroups of the LEAN form of the kernel
+                           (<= 48 VGPRs, gamma / beta re-read per row; bit-identical outputs), which fits beside a persistent GEMM workgroup of
+                           another stream on the same CU -- 256 = one per CU: the LayerNorm streams under that GEMM instead of taking turns
+                           with it (csrc/norm.hip) */
 } wj_ln_fwd_args;
 int wj_layernorm_fwd(const wj_ln_fwd_args*, void* stream);
 
@@ -363,20 +358,6 @@ typedef struct {
 } wj_spin_args;
 int wj_spin(const wj_spin_args*, void* stream);
 
-/* MEASUREMENT AID, not a collective: the on-GPU footprint of an all-reduce of `bytes` bytes at `buf`, for rehearsing on ONE GPU what
- * the gradient all-reduce of a data-parallel run (train.py:174-179) takes away from the kernels that run beside it.  `workgroups`
- * resident workgroups of 512 threads (RCCL runs one per channel; the CUs a data-parallel run keeps free of persistent GEMM workgroups)
- * read and rewrite the buffer IN PLACE `passes` times (2 = the reduce-scatter and all-gather legs: 2 x bytes read and written; the
- * values are unchanged), paced so that the launch lasts at least `min_ticks` ticks of the 100 MHz clock (bytes over an assumed bus
- * bandwidth; 0 = as fast as those CUs go).  No data leaves the GPU; nothing about xGMI is measured. */
-typedef struct {
-    void* buf;
-    int64_t bytes;       /* multiple of 16 */
-    int64_t min_ticks;
-    int32_t workgroups;  /* 1 .. 256 */
-    int32_t passes;      /* 1 .. 8 */
-} wj_collective_footprint_args;
-int wj_collective_footprint(const wj_collective_footprint_args*, void* stream);
 
 /* buf[rows[i]][0 .. row_bytes) = 0 for i < n_rows (restores the all-zero state of a sparse gradient buffer) */
 typedef struct {

@@ -611,6 +611,68 @@ def test_integration_md_ctypes_stub_matches_the_library():
     assert f"ABI version {_abi.DEFINES['WJ_ABI_VERSION']}" in text
 
 
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md section 2 holds ONE table of every WJ_* / WAVJEPA_* environment switch the sources read, with its build (release /
+    lab).  This test greps the sources: an undocumented getenv fails, a documented switch nobody reads fails, and a switch that csrc/
+    reads through plain getenv (i.e. in the release library) must be listed as release -- result-changing diagnostics belong behind
+    wj_lab_env_* (compiled to their defaults unless -DWJ_LAB)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sect = text[text.index("### Environment switches"):text.index("ABI version 16")]
+    rows = [ln for ln in sect.splitlines() if ln.startswith("| `")]
+    doc = {}
+    for ln in rows:
+        cells = [c.strip() for c in ln.strip("|").split("|")]
+        for name in re.findall(r"`((?:WJ|WAVJEPA)_[A-Z0-9_]+)`", cells[0]):
+            assert name not in doc, f"{name} is listed twice"
+            doc[name] = cells[1]
+    csrc_release, csrc_lab, py = set(), set(), set()
+    for f in glob.glob(os.path.join(root, "wavjepa_amd", "csrc", "*")):
+        src = open(f).read()
+        src = re.sub(r"//[^\n]*", "", src)                      # (comments mention switches of other files)
+        csrc_release |= set(re.findall(r'(?<![_a-z])getenv\("((?:WJ|WAVJEPA)_[A-Z0-9_]+)"\)', src))
+        csrc_lab |= set(re.findall(r'wj_lab_env_(?:int|str)\("(WJ_[A-Z0-9_]+)"', src))
+    files = glob.glob(os.path.join(root, "wavjepa_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(root, "hear_api", "**", "*.py"), recursive=True)
+    files += [os.path.join(root, f) for f in ("train.py", "denoise.py", "bench.py", "utils.py")]
+    for f in files:
+        for ln in open(f):
+            if "environ" in ln:
+                py |= set(re.findall(r"[\"']((?:WJ|WAVJEPA)_[A-Z0-9_]+)[\"']", ln))
+    assert csrc_release and csrc_lab and py
+    assert not (csrc_release & csrc_lab), csrc_release & csrc_lab
+    read = csrc_release | csrc_lab | py
+    assert read - set(doc) == set(), f"undocumented environment switches: {sorted(read - set(doc))}"
+    assert set(doc) - read == set(), f"documented but never read: {sorted(set(doc) - read)}"
+    for name in csrc_release | py:
+        assert doc[name].startswith("release"), (name, doc[name])
+    for name in csrc_lab - py:
+        assert doc[name].startswith("lab"), (name, doc[name])
+    # the diagnostics that change results are lab-only
+    for name in ("WJ_PERSIST_DIAG_NOSTORE", "WJ_PERSIST_STAMPS", "WJ_PERSIST_ACTIVE", "WJ_GEMM_VARIANT"):
+        assert name in csrc_lab and name not in csrc_release
+
+
+def test_release_library_exports_compute_and_query_entries_only():
+    """The release .so exports exactly what include/wavjepa_hip.h declares (+ wj_workspace_bytes): no diagnostic entry, no process-global
+    setter; the laboratory .so adds exactly the entries of include/wavjepa_hip_lab.h."""
+    import subprocess
+    from wavjepa_amd import _abi
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if " T wj_" in ln}
+
+    rel = exported(_abi.LIB_PATH)
+    assert rel == set(_abi.FUNCTIONS) | {"wj_workspace_bytes"}, (sorted(rel - set(_abi.FUNCTIONS)), sorted(set(_abi.FUNCTIONS) - rel))
+    for gone in ("wj_gemm_set_variant", "wj_gemm_set_persist_cus", "wj_debug_persist_stamps", "wj_collective_footprint"):
+        assert gone not in rel
+    lab = exported(_abi.LAB_LIB_PATH)
+    assert lab == rel | set(_abi.LAB_FUNCTIONS) and set(_abi.LAB_FUNCTIONS) == {"wj_debug_persist_stamps", "wj_collective_footprint"}
+    assert _abi.load_lab().wj_abi_version() == _abi.load().wj_abi_version() == _abi.DEFINES["WJ_ABI_VERSION"]
+
+
 def test_compiled_kernels_have_no_mfma_result_read_across_a_branch(tmp_path):
     """hipcc was seen to leave ONE wait state between an MFMA and the first VALU read of its result when a branch lay between them
     (attention forward, round 2: run-dependent softmax sums).  tools/mfma_hazard_scan.py walks the gfx950 assembly of every source

@@ -480,6 +480,35 @@ def test_layernorm_fwd_bwd(ops, M, D):
     assert relerr(dbias, dsb.float().sum(0)) < (1e-5 if M < 1000 else 2e-4)
 
 
+@pytest.mark.parametrize("M,D,wgs", [(61, 64, 4), (1000, 128, 256), (5003, 384, 256), (5003, 768, 256), (3001, 768, 16), (515, 1024, 8), (700, 512, 256)])
+def test_layernorm_fwd_lean_form_on_a_capped_grid(ops, M, D, wgs):
+    """wj_ln_fwd_args.workgroups: the lean (<= 48 VGPR) kernel on at most `wgs` workgroups -- the form that shares a CU with a persistent
+    GEMM of another stream.  Against fp32 torch math, and bit for bit what the full-grid kernel writes (same arithmetic in the same order)."""
+    x = rnd(M, D, seed=120)
+    r = rnd(M, D, dtype=torch.bfloat16, seed=121)
+    gamma = 1 + 0.1 * rnd(D, seed=122)
+    beta = 0.1 * rnd(D, seed=123)
+    outs = []
+    for cap in (0, wgs):
+        y = torch.full((M, D), float("nan"), device=dev())
+        yb = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=dev())
+        mean = torch.full((M,), float("nan"), device=dev())
+        rstd = torch.full((M,), float("nan"), device=dev())
+        ops.layernorm_fwd(x, gamma, beta, M=M, D=D, eps=1e-6, r=r, y_f32=y, y_bf16=yb, mean=mean, rstd=rstd, workgroups=cap)
+        outs.append((y, yb, mean, rstd))
+    ref = F.layer_norm(x + r.float(), (D,), gamma, beta, 1e-6)
+    assert relerr(outs[1][0], ref) < 1e-5
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # bf16 input, no residual, bf16 output only (the final norms)
+    xb = rnd(M, D, dtype=torch.bfloat16, seed=124)
+    y0 = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+    y1 = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.layernorm_fwd(xb, gamma, beta, M=M, D=D, eps=1e-5, y_bf16=y0, x_is_bf16=True)
+    ops.layernorm_fwd(xb, gamma, beta, M=M, D=D, eps=1e-5, y_bf16=y1, x_is_bf16=True, workgroups=wgs)
+    assert torch.equal(y0, y1)
+
+
 def test_layernorm_bf16_input_with_row_remap(ops):
     """feature_norms reads the conv tokens from the padded [N][P][C] buffer (P = T + 1)."""
     N, T, P, D = 3, 10, 11, 64
@@ -1250,6 +1279,64 @@ def test_collective_footprint_measurement_aid(ops):
     assert torch.equal(x, ref) and 1.9 < e0.elapsed_time(e1) < 4.0
     with pytest.raises(Exception):
         ops.collective_footprint(x, 24, workgroups=32)                       # not a multiple of 16 bytes
+
+
+@pytest.mark.timeout(60)
+def test_pair_and_persistent_gemms_finish_beside_a_long_lived_cu_holding_kernel(ops):
+    """The RCCL-channel shape on one GPU: ONE launch of 32 resident workgroups (wj_collective_footprint, the laboratory library's rehearsal
+    kernel, paced to last ~2 s) holds its CUs for the whole test, the way a collective's channel kernels do while they wait for a peer GPU.
+    Beside it, on two other streams: the K-split PAIR kernel (two workgroups per tile that spin on each other's flags -- forward progress
+    needs both roles resident; 234 workgroups for 256 CUs of which 32 are taken) and the persistent GEMM at 28 workgroups per XCD (the
+    data-parallel default, wj_gemm_args.persist_cus).  Everything must finish inside the time-out with the bits of the undisturbed run."""
+    M, N, K = 9945, 768, 3072                        # the ragged student's linear2: 39 x 3 = 117 tiles -> K-split pairs
+    A = rnd(M, K, dtype=torch.bfloat16, seed=71)
+    W = rnd(N, K, scale=0.03, dtype=torch.bfloat16, seed=72)
+    need = ops.workspace_bytes("wj_gemm_bf16", M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BF16)
+    assert need > 0
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev())
+    Mp, Np, Kp = 51200, 768, 768                     # the teacher's out_proj: 600 items on the persistent kernel
+    Ap = rnd(Mp, Kp, dtype=torch.bfloat16, seed=73)
+    Wp = rnd(Np, Kp, scale=0.05, dtype=torch.bfloat16, seed=74)
+
+    def run_pair(out):
+        ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, workspace=ws, schedule=3)
+
+    def run_persist(out):
+        ops.gemm(Ap, Wp, out, M=Mp, N=Np, K=Kp, lda=Kp, ldb=Kp, ldc=Np, schedule=4, persist_cus=28)
+
+    ref_pair = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ref_pers = torch.empty(Mp, Np, dtype=torch.bfloat16, device=dev())
+    run_pair(ref_pair)
+    run_persist(ref_pers)
+    torch.cuda.synchronize()
+    assert relerr(ref_pair.float(), A.float() @ W.float().t()) < 4e-3 and relerr(ref_pers.float(), Ap.float() @ Wp.float().t()) < 4e-3
+    hold = rnd(16 * 1024 * 1024, seed=75)            # 64 MB bucket, rewritten in place (values unchanged)
+    hold_ref = hold.clone()
+    s_hold, s_pair, s_pers = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    done_hold = torch.cuda.Event()
+    with torch.cuda.stream(s_hold):
+        ops.collective_footprint(hold, hold.numel() * 4, workgroups=32, passes=8, min_ticks=200_000_000)    # ~2 s of the 100 MHz clock
+        done_hold.record(s_hold)
+    import time
+    time.sleep(0.05)                                  # the holder is resident before the GEMMs are queued
+    outs_pair = [torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev()) for _ in range(4)]
+    outs_pers = [torch.full((Mp, Np), float("nan"), dtype=torch.bfloat16, device=dev()) for _ in range(4)]
+    for rep in range(24):
+        with torch.cuda.stream(s_pair):
+            run_pair(outs_pair[rep % 4])
+        with torch.cuda.stream(s_pers):
+            run_persist(outs_pers[rep % 4])
+    s_pair.synchronize()
+    s_pers.synchronize()
+    assert not done_hold.query(), "the CU-holding launch ended before the GEMMs did: nothing was tested"
+    for o in outs_pair:
+        assert torch.equal(o.view(torch.int16), ref_pair.view(torch.int16))
+    for o in outs_pers:
+        assert torch.equal(o.view(torch.int16), ref_pers.view(torch.int16))
+    torch.cuda.synchronize()
+    assert torch.equal(hold, hold_ref)
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0          # the pair flags are back at zero
 
 
 def test_gemm_persistent_counter_slots_are_recycled(ops):

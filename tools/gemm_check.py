@@ -6,6 +6,7 @@ against it a rare last-place difference of the bf16 output is allowed: <= 2 % of
 absolute where sum and bias cancel; + 4e-3 for the GELU outputs), and its own repetitions must be bit-identical to each other.  A race shows as a large difference
 in a few tiles.  Then interleaved timing rounds of both variants in one process."""
 import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import sys
 
 import torch

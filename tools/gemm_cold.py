@@ -2,6 +2,7 @@
 """A GEMM as the step sees it (GPU box): operands NOT resident in the Infinity Cache.  Every timed launch follows a 768 MB write to
 an unrelated buffer; compared with back-to-back (warm) launches.  usage: gemm_cold.py [variant ...]"""
 import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import sys
 
 import torch

@@ -3,6 +3,7 @@
 with the first.  A tile the scheduler skipped stays NaN; a tile computed from half-landed operands differs.  (This caught the
 mailbox write that could run ahead of the pull it publishes: about 1 launch in 40 skipped a tile.)"""
 import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import sys
 
 import torch

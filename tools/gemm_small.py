@@ -3,6 +3,7 @@
 variants 0 (256 x 128, two workgroups per CU), 2 (ping-pong), 3 (eight-phase), 4 (persistent, WJ_PERSIST_MIN_TILES=1) and the col-form B
 dgrad of the same product, warm (back to back) and cold (a 768 MB write in between), interleaved in one process."""
 import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import sys
 
 import torch

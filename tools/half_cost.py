@@ -2,6 +2,7 @@
 """What does a half-width work item of the persistent GEMM cost?  N = 256 (one full item per 256-row panel), 384 (full + half), 512 (two
 full) at the predictor's row count, cold operands, variant 4: cost(half) / cost(full) = (t384 - t256) / (t512 - t256)."""
 import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import sys
 
 import torch

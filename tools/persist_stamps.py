@@ -4,6 +4,7 @@ record s_memrealtime (100 MHz) at its start, after its prologue and after every 
 dispatch skew, the prologue, the first / steady / last tile durations, the tiles pulled per workgroup and the tail."""
 import ctypes
 import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import sys
 
 os.environ["WJ_PERSIST_STAMPS"] = "1"

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("WAVJEPA_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavjepa_amd", "lib", "libwavjepa_hip_lab.so"))  # laboratory build: honours the WJ_* A/B switches, exports the stamp reader
 import os, sys, ctypes, time
 os.environ["WJ_PERSIST_STAMPS"] = "1"
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, os.getcwd())

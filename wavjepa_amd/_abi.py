@@ -14,7 +14,10 @@ from typing import Dict, List, Tuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip.h")
+LAB_HEADER = os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip_lab.h")
 LIB_PATH = os.environ.get("WAVJEPA_HIP_LIB") or os.path.join(HERE, "lib", "libwavjepa_hip.so")   # override: A/B and ablation builds
+# the laboratory build of the same sources (-DWJ_LAB): extra diagnostic entries + every A/B switch; loaded only by load_lab()
+LAB_LIB_PATH = os.environ.get("WAVJEPA_HIP_LAB_LIB") or os.path.join(HERE, "lib", "libwavjepa_hip_lab.so")
 
 _SCALARS = {"int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "int": ctypes.c_int}
 
@@ -81,6 +84,7 @@ def parse_defines(path: str = HEADER) -> Dict[str, int]:
 
 _STRUCT_FIELDS, FUNCTIONS, ENUMS = parse_header()
 DEFINES = parse_defines()
+_LAB_STRUCT_FIELDS, LAB_FUNCTIONS, _ = parse_header(LAB_HEADER)
 
 
 def _make_struct(name: str, fields):
@@ -88,24 +92,39 @@ def _make_struct(name: str, fields):
 
 
 STRUCTS = {name: _make_struct(name, fields) for name, fields in _STRUCT_FIELDS.items()}
+LAB_STRUCTS = {name: _make_struct(name, fields) for name, fields in _LAB_STRUCT_FIELDS.items()}
 _NO_STREAM_FUNCS = {"wj_abi_version": [], "wj_device_count": [], "wj_struct_size": [ctypes.c_char_p],
-                    "wj_gemm_set_variant": [ctypes.c_int], "wj_gemm_set_persist_cus": [ctypes.c_int],
+                    "wj_debug_persist_stamps": [ctypes.c_void_p, ctypes.c_int],
                     "wj_ln_bwd_partial_rows": [ctypes.c_int, ctypes.c_int], "wj_scatter_fill_bwd_partial_rows": [ctypes.c_int, ctypes.c_int],
                     "wj_rccl_unique_id": [ctypes.c_void_p],
                     "wj_rccl_bucket_allreduce_init": [ctypes.c_void_p], "wj_rccl_bucket_allreduce_finalize": []}
 
 _lib = None
+_lab_lib = None
 
 
 def lib_path() -> str:
     return LIB_PATH
 
 
+def load_lab():
+    """The laboratory library (include/wavjepa_hip_lab.h): the release entries plus the diagnostic ones.  Used by tools/, the all-reduce
+    rehearsal (bench.py --emulate-allreduce) and the tests that dissect a kernel; never by the training / inference path."""
+    global _lab_lib
+    if _lab_lib is None:
+        _lab_lib = _load(LAB_LIB_PATH, FUNCTIONS + LAB_FUNCTIONS, {**STRUCTS, **LAB_STRUCTS})
+    return _lab_lib
+
+
 def load():
     """Load the library (once).  Raises WavJepaHipError when it is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
+    if _lib is None:
+        _lib = _load(LIB_PATH, FUNCTIONS, STRUCTS)
+    return _lib
+
+
+def _load(LIB_PATH: str, FUNCTIONS, STRUCTS):
     if not os.path.exists(LIB_PATH):
         raise WavJepaHipError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m wavjepa_amd.build` "
@@ -139,7 +158,6 @@ def load():
         want = lib.wj_struct_size(name.encode())
         if want != ctypes.sizeof(cls):
             raise WavJepaHipError(f"struct {name}: header mirror is {ctypes.sizeof(cls)} bytes, library says {want}")
-    _lib = lib
     return lib
 
 
@@ -154,7 +172,7 @@ def workspace_bytes(fn_name: str, args_struct) -> int:
 _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}
 
 
-def call(fn_name: str, args_struct, stream: int) -> None:
-    rc = getattr(load(), fn_name)(ctypes.byref(args_struct), stream)
+def call(fn_name: str, args_struct, stream: int, lab: bool = False) -> None:
+    rc = getattr(load_lab() if lab else load(), fn_name)(ctypes.byref(args_struct), stream)
     if rc != 0:
         raise WavJepaHipError(f"{fn_name} failed: {_ERR.get(rc, rc)}")

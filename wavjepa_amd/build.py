@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwavjepa_hip.so")
+LAB_LIB = os.path.join(LIBDIR, "libwavjepa_hip_lab.so")      # the same sources with -DWJ_LAB (include/wavjepa_hip_lab.h): diagnostics + A/B switches
 SOURCES = ["gemm.hip", "gemm_persist.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip", "rccl_bucket.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
@@ -29,12 +30,17 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
+    """The release library (compute + query entries, production-safe switches only), or with lab=True the laboratory variant
+    (libwavjepa_hip_lab.so: -DWJ_LAB, the extra entries of include/wavjepa_hip_lab.h and every A/B / diagnostic environment switch)."""
     hipcc = _hipcc()
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj_lab" if lab else "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_internal.h"), os.path.join(os.path.dirname(HERE), "include", "wavjepa_hip.h")]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_internal.h"), os.path.join(inc, "wavjepa_hip.h"), os.path.join(inc, "wavjepa_hip_lab.h")]
+    flags = FLAGS + (["-DWJ_LAB"] if lab else [])
+    lib = LAB_LIB if lab else LIB
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -44,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + flags + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
@@ -56,15 +62,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[wavjepa_amd.build] compiled {os.path.basename(s)}", file=sys.stderr)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
         if verbose:
-            print(f"[wavjepa_amd.build] linked {LIB}", file=sys.stderr)
-    build_io(force=force, verbose=verbose)
-    return LIB
+            print(f"[wavjepa_amd.build] linked {lib}", file=sys.stderr)
+    if not lab:
+        build_io(force=force, verbose=verbose)
+    return lib
+
+
+def build_all(force: bool = False, verbose: bool = True) -> None:
+    """Release + laboratory libraries (what __graft_entry__.build() and the test suite need)."""
+    build(force=force, verbose=verbose)
+    build(force=force, verbose=verbose, lab=True)
 
 
 IO_LIB = os.path.join(LIBDIR, "libwavjepa_io.so")
@@ -88,4 +101,7 @@ def build_io(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--release-only" in sys.argv:
+        build(force="--force" in sys.argv)
+    else:
+        build_all(force="--force" in sys.argv)

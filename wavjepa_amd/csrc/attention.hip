@@ -798,7 +798,7 @@ extern "C" int wj_attn_bwd(const wj_attn_bwd_args* a, void* stream) {
         if (a->hd == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 26>), grid, dim3(NWB64 * 64), lds, st, *a);
         else hipLaunchKernelGGL((attn_bwd_kernel<32, NWB32, 26>), grid, dim3(NWB32 * 64), lds, st, *a);
     } else if (a->T <= 128) {          // ragged student / predictor: at most 8 tiles (6 or 8 waves per workgroup measured 1.5-2x slower)
-        static const int frag = getenv("WJ_ATTN_BWD_FRAG") ? atoi(getenv("WJ_ATTN_BWD_FRAG")) : 3;   // bit 0: hd 32, bit 1: hd 64 (A/B switch)
+        static const int frag = wj_lab_env_int("WJ_ATTN_BWD_FRAG", 3);   // bit 0: hd 32, bit 1: hd 64 (A/B switch)
         const bool masked = a->key_mask != nullptr;
         if (a->hd == 64) {
             if (!(frag & 2)) hipLaunchKernelGGL((attn_bwd_kernel<64, NWB64, 8>), grid, dim3(NWB64 * 64), lds, st, *a);

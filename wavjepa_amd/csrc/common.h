@@ -31,6 +31,20 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
         }                                                                                              \
     } while (0)
 
+// Laboratory switches (A/B runs, diagnostics that change results or schedules): read from the environment ONLY in the -DWJ_LAB build
+// (libwavjepa_hip_lab.so, include/wavjepa_hip_lab.h); the release library compiles each to its default -- a production process cannot be
+// pushed onto a diagnostic path by a stray variable.  Switches that are safe in production use getenv directly and are listed in
+// INTEGRATION.md (tests/test_host_cpu.py checks both lists against the sources).
+#ifdef WJ_LAB
+constexpr bool WJ_LAB_BUILD = true;
+static inline int wj_lab_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline const char* wj_lab_env_str(const char* name) { return getenv(name); }
+#else
+constexpr bool WJ_LAB_BUILD = false;
+static inline int wj_lab_env_int(const char*, int dflt) { return dflt; }
+static inline const char* wj_lab_env_str(const char*) { return nullptr; }
+#endif
+
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv0_fold_kernel(const float* __restrict
 constexpr int STATS_SLOTS = 768;
 inline int stats_tcs(int N, int L_out, int C_in) {
     static int forced = -1;
-    if (forced < 0) { const char* v = getenv("WJ_CONV0_STATS_TCS"); forced = v ? atoi(v) : 0; }     // A/B runs (1024: the round-4 chunks)
+    if (forced < 0) forced = wj_lab_env_int("WJ_CONV0_STATS_TCS", 0);     // A/B runs (1024: the round-4 chunks)
     if (forced >= 32) return forced / 32 * 32;
     int chunks = (STATS_SLOTS + N / 2) / (N > 0 ? N : 1);
     const int most = (L_out + 255) / 256;
@@ -656,10 +656,10 @@ void launch_fwd(const wj_conv0_fwd_args* a, const Geo& g, int span_max, hipStrea
         hipLaunchKernelGGL(conv0_fold_kernel, dim3((unsigned)((rec + 1023) / 1024), a->N), dim3(256), 0, s, (const float*)part, chunks, rec,
                            sums, 2L * a->C, a->yx, (long)a->C * TAPS, a->x1, (const int32_t*)nullptr, 1);
     }
-    static const int use_mfma = [] { const char* e = getenv("WJ_CONV0_APPLY_MFMA"); return e ? atoi(e) : 1; }();   // 0: the VALU form (A/B runs)
+    static const int use_mfma = wj_lab_env_int("WJ_CONV0_APPLY_MFMA", 1);   // 0: the VALU form (A/B runs)
     if (use_mfma && a->C % 64 == 0 && TAPS <= 32) {
         const int span_a = (TCA - 1) * a->stride + a->k;
-        static const int occ = [] { const char* e = getenv("WJ_CONV0_APPLY_OCC"); return e ? atoi(e) : 1; }();      // 2: 128 VGPRs, two workgroups per CU -- measured 836 against 851 us alone and nothing on top of the re-chunked statistics pass (profiles/r05_conv0_variants.log): the pass is VALU-throughput-bound, not latency-bound
+        static const int occ = wj_lab_env_int("WJ_CONV0_APPLY_OCC", 1);      // 2: 128 VGPRs, two workgroups per CU -- measured 836 against 851 us alone and nothing on top of the re-chunked statistics pass (profiles/r05_conv0_variants.log): the pass is VALU-throughput-bound, not latency-bound
         if (occ >= 2)
             hipLaunchKernelGGL((conv0_apply_mfma_kernel<TAPS, 2>), dim3((a->P + TCA - 1) / TCA, a->N), dim3(512), (size_t)a->C_in * span_a * sizeof(bf16_t),
                                s, (const bf16_t*)a->audio, (const bf16_t*)a->w, a->gamma, a->beta, (const float*)sums, (bf16_t*)a->act, a->mean,

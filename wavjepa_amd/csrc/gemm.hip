@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(NT, (BN == 256 || BMT == 384) ? 1 : 2) void gemm3_g
 // the accumulators of four waves (32 registers x 64 lanes x 16 B each).
 int pair_min_k() {
     static int v = -1;
-    if (v < 0) { const char* s = getenv("WJ_PAIR_MIN_K"); v = s ? atoi(s) : 1536; }     // WJ_PAIR_MIN_K=1000000: pairs off (A/B runs)
+    if (v < 0) v = wj_lab_env_int("WJ_PAIR_MIN_K", 1536);     // lab build: WJ_PAIR_MIN_K=1000000 switches the pairs off (A/B runs)
     return v;
 }
 long pair_ws_need(int tiles) { return 4096L * ((tiles * 8 + 4095) / 4096) + (long)tiles * PAIR_TILE_BYTES; }
@@ -1291,13 +1291,12 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 //   3 = 256x256x64 tile, eight-phase     : row-form operands, K % 128 == 0 (+10..15 % over variant 2 at K = 768, +35 % at 8192^3)
 //   4 = variant 3's loop, persistent     : >= 256 work items; forward epilogues, plain BF16 and MUL_GELU_GRAD (+ column sums) for the
 //                                          row-form dgrads against W^T shadows (csrc/gemm_persist.hip)
-// WJ_GEMM_VARIANT=0|1|2|3 (or wj_gemm_set_variant) forces one (A/B runs; 1-3 need N % 256 == 0 to avoid wasted columns but
-// stay correct; a variant that cannot run a shape falls back to 0).
-int g_forced_variant = -2;   // -2: not initialised (WJ_GEMM_VARIANT decides), -1: automatic, >= 0: forced
-
+// wj_gemm_args.schedule = 1 + v forces variant v for that call (tests, tools/gemm_check.py; 1-3 need N % 256 == 0 to avoid wasted columns
+// but stay correct; a variant that cannot run a shape falls back to 3, then 0); the lab build also honours WJ_GEMM_VARIANT=v for calls
+// that leave the field 0.  The library keeps no selection state.
 int pick_variant(const wj_gemm_args* a) {
-    if (g_forced_variant == -2) { const char* v = getenv("WJ_GEMM_VARIANT"); g_forced_variant = v ? atoi(v) : -1; }
-    const int forced = g_forced_variant;
+    static const int env_forced = wj_lab_env_int("WJ_GEMM_VARIANT", -1);
+    const int forced = a->schedule > 0 ? a->schedule - 1 : env_forced;
     const bool ep_ok = !a->a_trans && !a->b_trans && a->K % 128 == 0 && a->split_k <= 1;   // eight-phase schedule (variant 3)
     if (forced == 4) return wj_gemm_persist_eligible(a) ? 4 : (ep_ok ? 3 : 0);
     if (forced == 3) return ep_ok ? 3 : 0;
@@ -1441,7 +1440,7 @@ extern "C" int wj_wgrad_grouped(const wj_wgrad_group_args* a, void* stream) {
     // every problem a multiple of 384 rows x 128 columns (the predictor: d = 384): the 384 x 128 tile has no half-empty row tiles
     // (WJ_WGRAD_384=0: the 256 x 128 tile, round 4; =2: the ping-pong schedule on the 384 x 128 tile)
     static int m384_mode = -1;
-    if (m384_mode < 0) { const char* v = getenv("WJ_WGRAD_384"); m384_mode = v ? atoi(v) : 1; }
+    if (m384_mode < 0) m384_mode = wj_lab_env_int("WJ_WGRAD_384", 1);
     if (m384 && m384_mode == 1) return launch_grouped<128, 384, 0>(a, (hipStream_t)stream);
     if (m384 && m384_mode == 2) return launch_grouped<128, 384, 1>(a, (hipStream_t)stream);
     return launch_grouped<128>(a, (hipStream_t)stream);
@@ -1451,12 +1450,6 @@ extern "C" int wj_wgrad_grouped(const wj_wgrad_group_args* a, void* stream) {
 int64_t wj_gemm_ws_bytes(const wj_gemm_args* a) {
     if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || !pair_shape(a)) return 0;
     return pair_ws_need(((a->M + BM - 1) / BM) * (a->N / 256));
-}
-
-extern "C" int wj_gemm_set_variant(int variant) {
-    const int prev = g_forced_variant;
-    g_forced_variant = variant < 0 ? -1 : variant;
-    return prev;
 }
 
 extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
@@ -1473,6 +1466,7 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD_Z && (!a->aux || !a->rowmap || ((uintptr_t)a->aux & 15))) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
     if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;
+    if (a->schedule < 0 || a->schedule > 5 || a->persist_cus < 0 || a->persist_cus > 32) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (a->rowmap) {
         // gather forms (sparse conv backward), one instantiation each

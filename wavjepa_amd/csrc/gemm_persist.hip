@@ -55,7 +55,9 @@ constexpr int CTR_STRIDE = 32;                    // dwords between the 8 counte
 __device__ unsigned g_sched_ctr[SLOTS * 8 * CTR_STRIDE];
 __device__ __attribute__((aligned(256))) unsigned char g_zero_bias[256];
 constexpr int STAMP_N = 64;
-__device__ unsigned long long g_stamps[2 * 256 * STAMP_N];   // diagnostic (WJ_PERSIST_STAMPS=1): start, end of prologue, end of every tile
+#ifdef WJ_LAB
+__device__ unsigned long long g_stamps[2 * 256 * STAMP_N];
+#endif   // diagnostic (WJ_PERSIST_STAMPS=1): start, end of prologue, end of every tile
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -383,7 +385,7 @@ __device__ __forceinline__ void epilogue_regs(f32x4 (&acc)[8][4], char* smem, co
     auto through_strip = [&](const u32x2 (&o)[NI], char* dst) {
         u32x4 lo, hi;
         transpose(o, lo, hi);
-        if (a.nostore) {                            // diagnostic: keep the values alive, issue no store
+        if (WJ_LAB_BUILD && a.nostore) {            // diagnostic (lab build): keep the values alive, issue no store
             asm volatile("" ::"v"(lo));
             if constexpr (!HALF) asm volatile("" ::"v"(hi));
             return;
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
     };
     int n_stamp = 0;
     auto stamp = [&]() {
-        if (a.stamps && t == 0 && n_stamp < STAMP_N - 2) {
+        if (WJ_LAB_BUILD && a.stamps && t == 0 && n_stamp < STAMP_N - 2) {
             a.stamps[blockIdx.x * STAMP_N + n_stamp] = __builtin_amdgcn_s_memrealtime();
             if (n_stamp == 1) a.stamps[blockIdx.x * STAMP_N + STAMP_N - 2] = __builtin_amdgcn_s_memtime();      // shader clock after the prologue ...
             a.stamps[blockIdx.x * STAMP_N + STAMP_N - 1] = __builtin_amdgcn_s_memtime();                          // ... and at the latest stamp
@@ -604,8 +606,8 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 
     f32x4 acc[8][4];                                   // defined by the first K tile of every output tile (C = 0 there)
 
-    if (a.stamps && (int)(blockIdx.x >> 3) >= a.active) return;   // diagnostic: a partly idle chip (WJ_PERSIST_ACTIVE)
-    if (a.stagger > 0) {
+    if (WJ_LAB_BUILD && a.stamps && (int)(blockIdx.x >> 3) >= a.active) return;   // diagnostic: a partly idle chip (WJ_PERSIST_ACTIVE)
+    if (WJ_LAB_BUILD && a.stagger > 0) {
         // All workgroups start together and every item takes the same time, so the whole chip alternates between a K-loop phase
         // (matrix pipe busy, HBM idle) and an epilogue phase (every CU reads / writes its 128-256 KB at once, matrix pipe idle).
         // Spreading the starts over one item time lets one workgroup's epilogue traffic travel while its neighbours multiply.
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 64 + g * 16);
         }
-        unsigned long long* st = (a.stamps && tile_iter < 7) ? a.stamps + 256 * STAMP_N + blockIdx.x * STAMP_N + tile_iter * 8 : nullptr;
+        unsigned long long* st = (WJ_LAB_BUILD && a.stamps && tile_iter < 7) ? a.stamps + 256 * STAMP_N + blockIdx.x * STAMP_N + tile_iter * 8 : nullptr;
         ++tile_iter;
         pp_tile<0, LAGF, LAGH, true>(acc, smem, s, nA, nB, y_skip, b1_skip, vx, vb, dx, db, a_lo, b_lo, false, 2 == n, has_next, lag, half0,
                                      false, pv, bv, st);
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
         if (wm == 1) __builtin_amdgcn_s_barrier();
         stamp();
         if (!has_next) break;
-        lag = a.nostore ? 3 : (half0 ? 2 : 1);         // every item issues all of its stores (edge tiles are shifted, not clipped)
+        lag = (WJ_LAB_BUILD && a.nostore) ? 3 : (half0 ? 2 : 1);         // every item issues all of its stores (edge tiles are shifted, not clipped)
         m0 = m1; n0 = n1; half0 = half1; skip0 = skip1;
         slot ^= 1;
         if (pulled) {
@@ -748,33 +750,29 @@ SlotTable& table() {
 // tile instead, the round-3 behaviour), or a full tile shifted inwards for any other remainder.
 struct Items { int items_n, half_item; };
 Items items_of(const wj_gemm_args* a) {
-    static int half_ok = -1;
-    if (half_ok < 0) { const char* v = getenv("WJ_PERSIST_HALF"); half_ok = v ? atoi(v) : 1; }
+    static const int half_ok = wj_lab_env_int("WJ_PERSIST_HALF", 1);
     Items it;
     it.half_item = (half_ok && a->N % 256 == 128) ? 1 : 0;
     it.items_n = it.half_item ? a->N / 256 + 1 : (a->N + 255) / 256;
     return it;
 }
 
-// Resident workgroups per XCD (WJ_PERSIST_CUS=n, 1..32, default 32 = one per CU).  A data-parallel run sets it below 32 so that an
-// RCCL channel kernel finds free CUs while a persistent GEMM is resident (bench.py --gpus N > 1 / trainer: WJ_PERSIST_CUS unset ->
-// wj_gemm_set_persist_cus).
-int g_persist_wpx = 0;
-int persist_wpx() {
-    if (g_persist_wpx == 0) {
+// Resident workgroups per XCD: wj_gemm_args.persist_cus (1..32) per call; 0 = the default, 32 = one per CU, or WJ_PERSIST_CUS=n read ONCE
+// (thread-safe static initialisation; no state that a later call can change).  A data-parallel run passes a value below 32 so that an RCCL
+// channel kernel finds free CUs while a persistent GEMM is resident (trainer.init_persist_cus).
+int persist_wpx(const wj_gemm_args* a) {
+    static const int dflt = [] {
         const char* v = getenv("WJ_PERSIST_CUS");
-        int w = v ? atoi(v) : 32;
-        g_persist_wpx = w < 1 ? 1 : (w > 32 ? 32 : w);
-    }
-    return g_persist_wpx;
+        const int w = v ? atoi(v) : 32;
+        return w < 1 ? 1 : (w > 32 ? 32 : w);
+    }();
+    return a->persist_cus > 0 ? (a->persist_cus > 32 ? 32 : a->persist_cus) : dflt;
 }
 
-// Start-up spread in ticks of the 100 MHz clock.  WJ_PERSIST_STAGGER_US=<us> applies to every launch; unset: 0.
+// Start-up spread in ticks of the 100 MHz clock (lab build only).  WJ_PERSIST_STAGGER_US=<us> applies to every launch; unset: 0.
 int persist_stagger(const wj_gemm_args* a) {
-    static int us = -1;
-    if (us < 0) { const char* v = getenv("WJ_PERSIST_STAGGER_US"); us = v ? atoi(v) : 0; }
-    static int only = -2;                           // WJ_PERSIST_STAGGER_EPI=<epilogue>: only launches with that epilogue (A/B runs)
-    if (only == -2) { const char* v = getenv("WJ_PERSIST_STAGGER_EPI"); only = v ? atoi(v) : -1; }
+    static const int us = wj_lab_env_int("WJ_PERSIST_STAGGER_US", 0);
+    static const int only = wj_lab_env_int("WJ_PERSIST_STAGGER_EPI", -1);   // only launches with that epilogue (A/B runs)
     if (only >= 0 && a->epilogue != only) return 0;
     return us * 100;
 }
@@ -790,7 +788,7 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
     const Items it = items_of(a);
     p.items_n = it.items_n; p.half_item = it.half_item;
     p.ntiles = ((a->M + 255) / 256) * p.items_n;
-    p.wpx = persist_wpx();
+    p.wpx = persist_wpx(a);
     p.stagger = persist_stagger(a);
     {
         // Blocked tile order for shapes with N >= 2304 whose per-XCD run of items is whole panels and whose item count per panel is a
@@ -800,7 +798,7 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
         static int wbp = -1, wbc = 0;
         if (wbp < 0) {
             wbp = 8; wbc = 4;
-            const char* v = getenv("WJ_PERSIST_WBLOCK");
+            const char* v = wj_lab_env_str("WJ_PERSIST_WBLOCK");
             if (v) { int x = 0, y = 0; wbp = 0; if (sscanf(v, "%dx%d", &x, &y) == 2 && x > 0 && y > 0) { wbp = x; wbc = y; } }
         }
         p.wb_panels = 0; p.wb_cols = 0;
@@ -808,22 +806,22 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
         if (wbp > 0 && a->N >= 2304 && !p.half_item && panels % 8 == 0 && p.items_n % wbc == 0) { p.wb_panels = wbp; p.wb_cols = wbc; }
     }
     {
-        static int ns = -1;
-        if (ns < 0) { const char* v = getenv("WJ_PERSIST_DIAG_NOSTORE"); ns = v ? atoi(v) : 0; }
+        static const int ns = wj_lab_env_int("WJ_PERSIST_DIAG_NOSTORE", 0);
         p.nostore = (ns && a->epilogue != WJ_EPI_MUL_GELU_GRAD) ? 1 : 0;
     }
     p.seg_rows = a->seg_rows > 0 ? a->seg_rows : 1;
     p.seg_valid = a->seg_rows > 0 ? a->seg_valid : 1;
     {
-        static int stamps = -1;                     // WJ_PERSIST_STAMPS=1: diagnostic time stamps (tools/persist_stamps.py)
-        if (stamps < 0) { const char* v = getenv("WJ_PERSIST_STAMPS"); stamps = v ? atoi(v) : 0; }
+        static const int stamps = wj_lab_env_int("WJ_PERSIST_STAMPS", 0);   // lab build, WJ_PERSIST_STAMPS=1: diagnostic time stamps (tools/persist_stamps.py)
         p.stamps = nullptr;
         p.active = 32;
         if (stamps) {
-            const char* av = getenv("WJ_PERSIST_ACTIVE");
+            const char* av = wj_lab_env_str("WJ_PERSIST_ACTIVE");
             if (av) p.active = atoi(av);
+#ifdef WJ_LAB
             void* sp = nullptr;
             if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_stamps)) == hipSuccess) p.stamps = (unsigned long long*)sp;
+#endif
         }
     }
     auto kern = gemm_persist_kernel<EPI>;
@@ -858,20 +856,14 @@ bool wj_gemm_persist_eligible(const wj_gemm_args* a) {
     // aligned A / B / C; stated here as well because the shifted / half-width edge items start at N - 256 / N - 128)
     if ((a->N & 7) || (a->lda & 7) || (a->ldb & 7) || (a->ldc & 7)) return false;
     if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C | (uintptr_t)a->C2 | (uintptr_t)a->bias) & 15) return false;
-    static int min_tiles = -1;                      // WJ_PERSIST_MIN_TILES: smallest item count that takes the persistent kernel
-    if (min_tiles < 0) { const char* v = getenv("WJ_PERSIST_MIN_TILES"); min_tiles = v ? atoi(v) : 256; }
+    static const int min_tiles = wj_lab_env_int("WJ_PERSIST_MIN_TILES", 256);   // smallest item count that takes the persistent kernel
     const long tiles = (long)((a->M + 255) / 256) * items_of(a).items_n;
     if (tiles < min_tiles) return false;
     if (a->lda * 2 * 256 >= (1l << 31) || a->ldb * 2 * 256 >= (1l << 31)) return false;   // 32-bit per-lane offsets inside a tile
     return true;
 }
 
-extern "C" int wj_gemm_set_persist_cus(int workgroups_per_xcd) {
-    const int prev = persist_wpx();
-    if (workgroups_per_xcd > 0) g_persist_wpx = workgroups_per_xcd > 32 ? 32 : workgroups_per_xcd;
-    return prev;
-}
-
+#ifdef WJ_LAB
 // diagnostic: copy the stamp buffer to the host (synchronises the device)
 extern "C" int wj_debug_persist_stamps(unsigned long long* out, int n) {
     if (!out || n <= 0) return WJ_ERR_ARG;
@@ -880,6 +872,7 @@ extern "C" int wj_debug_persist_stamps(unsigned long long* out, int n) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8) != hipSuccess) return WJ_ERR_LAUNCH;
     return WJ_OK;
 }
+#endif
 
 int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
     if (!wj_gemm_persist_eligible(a)) return WJ_ERR_UNSUPPORTED;

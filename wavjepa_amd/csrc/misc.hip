@@ -4,6 +4,9 @@
 #include <string.h>
 #include "common.h"
 #include "../../include/wavjepa_hip.h"
+#ifdef WJ_LAB
+#include "../../include/wavjepa_hip_lab.h"
+#endif
 
 namespace {
 
@@ -596,7 +599,10 @@ extern "C" int wj_struct_size(const char* name) {
     WJ_SZ(wj_add_pos_args) WJ_SZ(wj_gather_args) WJ_SZ(wj_scatter_fill_args) WJ_SZ(wj_scatter_fill_bwd_args)
     WJ_SZ(wj_unmask_rows_args) WJ_SZ(wj_instnorm_args) WJ_SZ(wj_mse_args) WJ_SZ(wj_ema_args) WJ_SZ(wj_sumsq_args)
     WJ_SZ(wj_adamw_args) WJ_SZ(wj_cast_args) WJ_SZ(wj_crop_args) WJ_SZ(wj_zero_rows_args) WJ_SZ(wj_instnorm_mean_args) WJ_SZ(wj_spin_args)
-    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args) WJ_SZ(wj_colsum_group_args) WJ_SZ(wj_rccl_init_args) WJ_SZ(wj_rccl_launch_args) WJ_SZ(wj_rccl_wait_args) WJ_SZ(wj_collective_footprint_args)
+    WJ_SZ(wj_gemm_fp8_args) WJ_SZ(wj_quantize_fp8_args) WJ_SZ(wj_wgrad_group_args) WJ_SZ(wj_rir_conv_args) WJ_SZ(wj_snr_mix_args) WJ_SZ(wj_resample_args) WJ_SZ(wj_mse_groups_args) WJ_SZ(wj_transpose_args) WJ_SZ(wj_colsum_group_args) WJ_SZ(wj_rccl_init_args) WJ_SZ(wj_rccl_launch_args) WJ_SZ(wj_rccl_wait_args)
+#ifdef WJ_LAB
+    WJ_SZ(wj_collective_footprint_args)
+#endif
 #undef WJ_SZ
     return -1;
 }
@@ -670,6 +676,7 @@ extern "C" int wj_spin(const wj_spin_args* a, void* stream) {
     return WJ_OK;
 }
 
+#ifdef WJ_LAB
 // the footprint of a collective on its GPU (see the header): `passes` in-place read + rewrite sweeps by a few resident workgroups,
 // stretched to `min_ticks` of the 100 MHz clock by pacing every piece
 typedef __attribute__((ext_vector_type(4))) unsigned cf_u32x4;
@@ -713,6 +720,7 @@ extern "C" int wj_collective_footprint(const wj_collective_footprint_args* a, vo
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }
+#endif
 
 extern "C" int wj_zero_rows(const wj_zero_rows_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();

@@ -164,6 +164,74 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(wj_ln_fwd_args a) {
     }
 }
 
+// The LEAN form (wj_ln_fwd_args.workgroups > 0): the same arithmetic in the same order -- bit-identical outputs -- from a kernel that fits
+// beside a persistent GEMM workgroup of ANOTHER stream on the same CU.  Such a workgroup (csrc/gemm_persist.hip) holds 2 x 224-232 of a
+// SIMD's 512 VGPRs and 150 of the CU's 160 KB of LDS for the whole launch: what is left is one wave of <= 48 registers per SIMD and a few
+// KB of LDS.  ln_fwd_kernel (78-100 VGPRs) therefore never runs beside it: the forward's LayerNorms -- HBM-bound, matrix pipe idle -- and
+// the other stream's GEMMs -- matrix-bound, HBM mostly idle -- take turns on the chip.  This form keeps gamma / beta in memory (3 KB,
+// L1-resident; re-read per row), has no fp8 / group-statistics / row-remap paths, and is launched with a grid capped by the caller (one
+// workgroup per CU = one wave per SIMD): it takes the bandwidth the GEMM leaves idle and never the CU slots the next persistent launch needs.
+template <int V, int LPR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void ln_fwd_lean_kernel(wj_ln_fwd_args a) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % LPR, sr = lane / LPR;
+    const int D = a.D;
+    const float invD = 1.0f / (float)D;
+    for (int m = (blockIdx.x * 4 + wave) * RPW + sr; m < a.M; m += gridDim.x * 4 * RPW) {
+        f32x4 s[V];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
+            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col < D) {
+                s[j] = load4(a.x, (long)m, D, col, a.x_is_bf16);
+                if (a.r) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4*>((const bf16_t*)a.r + (long)m * D + col);
+                    s[j] += f32x4{bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+                }
+                sum += s[j][0] + s[j][1] + s[j][2] + s[j][3];
+            }
+        }
+        const float mean = row_sum<V, LPR>(sum) * invD;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
+            if (col < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = s[j][e] - mean;
+                    sq += d * d;
+                }
+            }
+        }
+        const float var = row_sum<V, LPR>(sq) * invD;
+        const float rstd = rsqrtf(var + a.eps);
+        if (li == 0) {
+            if (a.mean) a.mean[m] = mean;
+            if (a.rstd) a.rstd[m] = rstd;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int col = li * 4 + LPR * 4 * j;
+            if (col < D) {
+                const f32x4 gam = *reinterpret_cast<const f32x4*>(a.gamma + col);
+                const f32x4 bet = *reinterpret_cast<const f32x4*>(a.beta + col);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (s[j][e] - mean) * rstd * gam[e] + bet[e];
+                if (a.y_f32) *reinterpret_cast<f32x4*>(a.y_f32 + (long)m * D + col) = y;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(y[e]);
+                if (a.y_bf16) *reinterpret_cast<bf16x4*>((bf16_t*)a.y_bf16 + (long)m * D + col) = o;
+            }
+        }
+    }
+}
+
 constexpr int BWD_THREADS = 256;
 
 // LPR lanes per row, TWO row slots in flight per wave (independent load streams ahead of the shuffle reductions), V float4
@@ -431,6 +499,23 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
     if (a->group_stats) grid = ((a->M + a->group_rows - 1) / a->group_rows) * GS_SPLIT;
     dim3 g(grid), b(256);
     hipStream_t s = (hipStream_t)stream;
+    if (a->workgroups > 0 && !a->group_stats && !a->y_fp8 && a->in_seg <= 0) {
+        // the lean form on a capped grid (see ln_fwd_lean_kernel): same bits, a kernel that shares a CU with a persistent GEMM
+        dim3 gl(grid < a->workgroups ? grid : a->workgroups);
+        if (half) {
+            if (a->D == 128) hipLaunchKernelGGL((ln_fwd_lean_kernel<1, 32>), gl, b, 0, s, *a);
+            else hipLaunchKernelGGL((ln_fwd_lean_kernel<3, 32>), gl, b, 0, s, *a);
+        } else {
+            switch ((a->D + 255) / 256) {
+                case 1: hipLaunchKernelGGL((ln_fwd_lean_kernel<1, 64>), gl, b, 0, s, *a); break;
+                case 2: hipLaunchKernelGGL((ln_fwd_lean_kernel<2, 64>), gl, b, 0, s, *a); break;
+                case 3: hipLaunchKernelGGL((ln_fwd_lean_kernel<3, 64>), gl, b, 0, s, *a); break;
+                default: hipLaunchKernelGGL((ln_fwd_lean_kernel<4, 64>), gl, b, 0, s, *a); break;
+            }
+        }
+        WJ_CHECK_LAUNCH();
+        return WJ_OK;
+    }
     if (half) {
         if (a->D == 128) hipLaunchKernelGGL((ln_fwd_kernel<1, 32>), g, b, 0, s, *a);
         else hipLaunchKernelGGL((ln_fwd_kernel<3, 32>), g, b, 0, s, *a);
@@ -448,10 +533,7 @@ extern "C" int wj_layernorm_fwd(const wj_ln_fwd_args* a, void* stream) {
 
 // partial rows wj_layernorm_bwd leaves in its workspace ([rows][3][D]) for M token rows of width D: its grid
 static int ln_bwd_one_pass_rows() {   // WJ_LN_BWD_ONE_PASS_ROWS: launches of at most this many row slots give every wave ONE pass (0 = never)
-    static const int v = [] {
-        const char* e = getenv("WJ_LN_BWD_ONE_PASS_ROWS");
-        return e ? atoi(e) : 16384;
-    }();
+    static const int v = wj_lab_env_int("WJ_LN_BWD_ONE_PASS_ROWS", 16384);
     return v;
 }
 static int ln_bwd_grid(int M, int D) {

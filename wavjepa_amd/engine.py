@@ -366,6 +366,15 @@ class JepaEngine:
         self.fuse_add_pos = _os.environ.get("WJ_FUSE_ADD_POS", "1") != "0"     # 0: mapper GEMM + wj_add_pos as two launches
         self.mapper_wgrad_side = _os.environ.get("WJ_MAPPER_WGRAD_SIDE", "1") != "0"
         self.conv_wgrad_side = _os.environ.get("WJ_CONV_WGRAD_SIDE", "1") != "0"   # 0: the sparse conv weight gradients on the main stream
+        # LayerNorm forward in its LEAN form on a capped grid (wj_ln_fwd_args.workgroups; csrc/norm.hip) for the stacks named in WJ_LN_LEAN
+        # ("tea", "enc", "dec", joined by + or ,; default: none): a kernel of <= 48 VGPRs shares a CU with the persistent GEMM workgroups of
+        # the OTHER stream (teacher beside student / predictor).  Measured (round 6, interleaved, one box): 45.79 ms/step without, 47.05 with
+        # all three, 45.91 teacher only, 47.63 student + predictor only, 45.94 with a cap of 1024 -- a capped LayerNorm alone on its stream's
+        # critical path loses more than it hides (DESIGN_EXPERIMENTS.md); off.  WJ_LN_LEAN_WGS: the cap (256 = one workgroup per CU).
+        lean = _os.environ.get("WJ_LN_LEAN", "")
+        self.ln_lean = {t.strip() for t in lean.replace("+", ",").split(",") if t.strip() and t.strip() != "0"} if self.use_side else set()
+        self.ln_lean_wgs = int(_os.environ.get("WJ_LN_LEAN_WGS", "256"))
+        self._lean_now = False                 # set inside the training forward only: inference runs one stream, nothing to stream under
         self._folds = []
         self._bind_params()
         self._bind_wt()
@@ -761,7 +770,8 @@ class JepaEngine:
             self._gemm8(qs, ss, w.wo, a.p, M=M, N=D, K=D, bias=w.bo)
         else:
             self._linear_fwd(stack, o_in, w.wo, a.p, M=M, N=D, K=D, bias=w.bo)
-        ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1, **f8_out)
+        lean = self.ln_lean_wgs if (self._lean_now and stack in self.ln_lean and not f8) else 0
+        ops.layernorm_fwd(x_in, w.g1, w.be1, M=M, D=D, eps=eps, r=a.p, y_f32=a.x1, y_bf16=a.x1b, mean=a.m1, rstd=a.r1, workgroups=lean, **f8_out)
         if f8:
             gq = dict(q_out=qb, q_scales=sb, ld_q_scale=M)
             if save:
@@ -778,7 +788,8 @@ class JepaEngine:
         # x2_out / x2_stats (teacher): the layer output goes to its own buffer and its per-clip (sum, sum of squares) is
         # accumulated on the way, so that the targets are ONE pass over the kept layers (wj_instnorm_mean)
         ops.layernorm_fwd(a.x1, w.g2, w.be2, M=M, D=D, eps=eps, r=a.f, y_f32=a.x2 if x2_out is None else x2_out, y_bf16=a.x2b,
-                          mean=a.m2, rstd=a.r2, group_stats=x2_stats, group_rows=self.T if x2_stats is not None else 0, **f8_out)
+                          mean=a.m2, rstd=a.r2, group_stats=x2_stats, group_rows=self.T if x2_stats is not None else 0,
+                          workgroups=lean if x2_stats is None else 0, **f8_out)
         return f8 and sub is None              # the small fp8 buffer now holds x2 for the next layer of this stack
 
     def _gemm8(self, q, sc, w_ptr: int, out, *, M: int, N: int, K: int, bias, epilogue: int = ops.EPI_BF16, C2=None, **extra) -> None:
@@ -1023,6 +1034,17 @@ class JepaEngine:
         self.audio = audio
         M, Mp, T, G = self.M, self.Mp, self.T, self.G
         De, Dd = c.d_enc, c.d_dec
+        self._lean_now = self.use_side
+        try:
+            self._forward_body(audio, plan)
+        finally:
+            self._lean_now = False
+
+    def _forward_body(self, audio: torch.Tensor, plan: MaskPlan) -> None:
+        c, f = self.cfg, self.flat
+        N = audio.shape[0]
+        M, Mp, T, G = self.M, self.Mp, self.T, self.G
+        De, Dd = c.d_enc, c.d_dec
         self._frontend(audio)
         # EMA teacher on the same local features (no mask, no final norm), joint instance-norm, mean of the last k layers:
         # independent of the student / predictor chain below, so it runs beside it on the side stream
@@ -1054,7 +1076,8 @@ class JepaEngine:
                 xq = self._layer_fwd(w, a, x, xb, Me, De, c.h_enc, N, None, eseq, xq_ready=xq)
                 x, xb = a.x2, a.x2b
             ops.layernorm_fwd(x, f.ptr32("encoder.norm.weight"), f.ptr32("encoder.norm.bias"), M=Me, D=De, eps=c.norm_eps,
-                              y_bf16=self.ctx_in, mean=self.enc_fm, rstd=self.enc_fr)
+                              y_bf16=self.ctx_in, mean=self.enc_fm, rstd=self.enc_fr,
+                              workgroups=self.ln_lean_wgs if (self._lean_now and "enc" in self.ln_lean) else 0)
         else:
             # student encoder over every token (keys restricted to the context), then the boolean-mask gather
             x, xb = self.lf, self.lf_b
@@ -1088,7 +1111,8 @@ class JepaEngine:
         if self.tail is not None:
             Mo = plan.n_tgt
         ops.layernorm_fwd(x, f.ptr32("decoder.norm.weight"), f.ptr32("decoder.norm.bias"), M=Mo, D=Dd, eps=c.norm_eps,
-                          y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr)
+                          y_bf16=self.dec_out_b, mean=self.dec_fm, rstd=self.dec_fr,
+                          workgroups=self.ln_lean_wgs if (self._lean_now and "dec" in self.ln_lean) else 0)
         ops.gemm(self.dec_out_b, f.ptr16("decoder_to_encoder_mapper.weight"), self.preds, M=Mo, N=De, K=Dd, lda=Dd, ldb=Dd,
                  ldc=De, bias=f.ptr32("decoder_to_encoder_mapper.bias"))
         self._join_side()               # teacher targets (side stream) are needed by the loss

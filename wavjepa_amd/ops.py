@@ -86,17 +86,17 @@ class TimingEvent:
             pass
 
 
-def _run(fn: str, struct_name: str, stream: Optional[int], **fields) -> None:
-    a = STRUCTS[struct_name]()
+def _run(fn: str, struct_name: str, stream: Optional[int], _lab: bool = False, **fields) -> None:
+    a = (_abi.LAB_STRUCTS if _lab else STRUCTS)[struct_name]()
     for k, v in fields.items():
         setattr(a, k, v)
     if PROFILE is None:
-        _abi.call(fn, a, _stream() if stream is None else stream)
+        _abi.call(fn, a, _stream() if stream is None else stream, lab=_lab)
         return
     s = _stream() if stream is None else stream
     e0, e1 = TimingEvent(), TimingEvent()
     e0.record(s)
-    _abi.call(fn, a, s)
+    _abi.call(fn, a, s, lab=_lab)
     e1.record(s)
     PROFILE.append((fn, fields, e0, e1))
 
@@ -122,13 +122,18 @@ def workspace_bytes(fn: str, **dims) -> int:
 def gemm(A: Ptr, B: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, a_trans: int = 0,
          b_trans: int = 0, epilogue: int = EPI_BF16, C2: Ptr = None, bias: Ptr = None, aux: Ptr = None, split_k: int = 1,
          seg_rows: int = 0, seg_valid: int = 0, alpha: float = 1.0, colsum: Ptr = None, rowmap: Ptr = None,
-         workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
-    """workspace: a zero-initialised byte tensor the library may use for K-split pairs (see include/wavjepa_hip.h: wj_gemm_args)."""
+         workspace: Optional[torch.Tensor] = None, schedule: Optional[int] = None, persist_cus: Optional[int] = None,
+         stream: Optional[int] = None) -> None:
+    """workspace: a zero-initialised byte tensor the library may use for K-split pairs (see include/wavjepa_hip.h: wj_gemm_args).
+    schedule: force tile / schedule variant 0..4 for this call (None: this binding's default, gemm_set_variant; -1: the library picks);
+    persist_cus: resident persistent-GEMM workgroups per XCD (None: this binding's default, gemm_set_persist_cus)."""
+    sched = _GEMM_SCHEDULE if schedule is None else int(schedule)
     _run("wj_gemm_bf16", "wj_gemm_args", stream, A=_p(A), B=_p(B), C=_p(C), C2=_p(C2), bias=_p(bias), aux=_p(aux), colsum=_p(colsum),
          rowmap=_p(rowmap),
          lda=lda, ldb=ldb, ldc=ldc, M=M, N=N, K=K, a_trans=a_trans, b_trans=b_trans, epilogue=epilogue, split_k=split_k,
          seg_rows=seg_rows, seg_valid=seg_valid, alpha=alpha, workspace=_p(workspace),
-         workspace_bytes=0 if workspace is None else workspace.numel() * workspace.element_size())
+         workspace_bytes=0 if workspace is None else workspace.numel() * workspace.element_size(),
+         schedule=0 if sched < 0 else sched + 1, persist_cus=_PERSIST_CUS if persist_cus is None else int(persist_cus))
 
 
 def gemm_mxfp8(A8: Ptr, B8: Ptr, scale_a: Ptr, scale_b: Ptr, C: Ptr, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
@@ -171,9 +176,18 @@ def wgrad_grouped(problems, stream: Optional[int] = None) -> None:
                                              bytes=sum(2.0 * p[5] * (p[3] + p[4]) + 4.0 * p[3] * p[4] for p in problems)), e0, e1))
 
 
+# Defaults this BINDING fills into wj_gemm_args.schedule / .persist_cus of every gemm() call that does not name them.  The library itself
+# keeps no such state (round 5's wj_gemm_set_variant / wj_gemm_set_persist_cus were process-global setters behind a re-entrant ABI).
+_GEMM_SCHEDULE = -1      # -1: the library picks; 0..4: force that variant (tests, tools/gemm_check.py)
+_PERSIST_CUS = 0         # 0: the library's default (32, or WJ_PERSIST_CUS); 1..32: resident persistent-GEMM workgroups per XCD
+
+
 def gemm_set_variant(variant: int) -> int:
-    """Force the GEMM tile/schedule variant (A/B runs); -1 = automatic.  Returns the previous setting."""
-    return int(_abi.load().wj_gemm_set_variant(int(variant)))
+    """Force the GEMM tile/schedule variant for the calls of this process's binding (tests, A/B runs); -1 = automatic.  Returns the
+    previous setting.  Per call: gemm(..., schedule=v)."""
+    global _GEMM_SCHEDULE
+    prev, _GEMM_SCHEDULE = _GEMM_SCHEDULE, (-1 if variant < 0 else int(variant))
+    return prev
 
 
 def transpose_bf16(src: Ptr, dst: Ptr, table: torch.Tensor, n_mats: int, n_tiles: int, stream: Optional[int] = None) -> None:
@@ -183,8 +197,14 @@ def transpose_bf16(src: Ptr, dst: Ptr, table: torch.Tensor, n_mats: int, n_tiles
 
 
 def gemm_set_persist_cus(workgroups_per_xcd: int) -> int:
-    """Resident workgroups per XCD of the persistent GEMM (1..32; <= 0 only queries).  Returns the previous value."""
-    return int(_abi.load().wj_gemm_set_persist_cus(int(workgroups_per_xcd)))
+    """Resident workgroups per XCD of the persistent GEMM for the calls of this binding (1..32; <= 0 only queries).  Returns the value that
+    was in effect (32 when neither this nor WJ_PERSIST_CUS has set one)."""
+    global _PERSIST_CUS
+    import os
+    prev = _PERSIST_CUS or max(1, min(32, int(os.environ.get("WJ_PERSIST_CUS", "32") or 32)))
+    if workgroups_per_xcd > 0:
+        _PERSIST_CUS = min(32, int(workgroups_per_xcd))
+    return prev
 
 
 def pick_split_k(M: int, N: int, K: int) -> int:
@@ -200,11 +220,11 @@ def pick_split_k(M: int, N: int, K: int) -> int:
 def layernorm_fwd(x: Ptr, gamma: Ptr, beta: Ptr, *, M: int, D: int, eps: float, r: Ptr = None, y_f32: Ptr = None,
                   y_bf16: Ptr = None, mean: Ptr = None, rstd: Ptr = None, x_is_bf16: bool = False, in_seg: int = 0,
                   in_valid: int = 0, group_stats: Ptr = None, group_rows: int = 0, in_chan: int = 0, y_fp8: Ptr = None,
-                  y_fp8_scales: Ptr = None, ld_fp8_scale: int = 0, stream: Optional[int] = None) -> None:
+                  y_fp8_scales: Ptr = None, ld_fp8_scale: int = 0, workgroups: int = 0, stream: Optional[int] = None) -> None:
     _run("wj_layernorm_fwd", "wj_ln_fwd_args", stream, x=_p(x), r=_p(r), gamma=_p(gamma), beta=_p(beta), y_f32=_p(y_f32),
          y_bf16=_p(y_bf16), mean=_p(mean), rstd=_p(rstd), group_stats=_p(group_stats), y_fp8=_p(y_fp8), y_fp8_scales=_p(y_fp8_scales),
          ld_fp8_scale=ld_fp8_scale, M=M, D=D, x_is_bf16=int(x_is_bf16), in_seg=in_seg, in_valid=in_valid, group_rows=group_rows,
-         in_chan=in_chan, eps=eps)
+         in_chan=in_chan, eps=eps, workgroups=int(workgroups))
 
 
 def layernorm_bwd(dy: Ptr, x: Ptr, gamma: Ptr, mean: Ptr, rstd: Ptr, *, M: int, D: int, r: Ptr = None, dy2: Ptr = None,
@@ -333,8 +353,9 @@ def spin(ticks: int, stream: Optional[int] = None) -> None:
 
 def collective_footprint(buf: Ptr, nbytes: int, *, workgroups: int = 32, passes: int = 2, min_ticks: int = 0,
                          stream: Optional[int] = None) -> None:
-    """Measurement aid (bench.py --emulate-allreduce): the on-GPU footprint of an all-reduce of `nbytes` at `buf`, see the header."""
-    _run("wj_collective_footprint", "wj_collective_footprint_args", stream, buf=_p(buf), bytes=int(nbytes), min_ticks=int(min_ticks),
+    """Measurement aid (bench.py --emulate-allreduce): the on-GPU footprint of an all-reduce of `nbytes` at `buf`; an entry of the LABORATORY
+    library (include/wavjepa_hip_lab.h), loaded on first use."""
+    _run("wj_collective_footprint", "wj_collective_footprint_args", stream, _lab=True, buf=_p(buf), bytes=int(nbytes), min_ticks=int(min_ticks),
          workgroups=int(workgroups), passes=int(passes))
 
 
