@@ -459,12 +459,12 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     s = block_sum(s, red);
     if (threadIdx.x == 0) ws[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int n) {
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int n, int accumulate) {
     __shared__ float red[16];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 1024) s += ws[i];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) out[0] = s;
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(wj_adamw_args a) {
@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(wj_adamw_args a) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i * 4);
         const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i * 4);
+        if (a.zero_grad) *reinterpret_cast<f32x4*>(a.g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i * 4);
         f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i * 4);
 #pragma unroll
@@ -848,9 +849,10 @@ extern "C" int wj_ema_update(const wj_ema_args* a, void* stream) {
 extern "C" int wj_grad_sumsq(const wj_sumsq_args* a, void* stream) {
     WJ_CLEAR_STALE_ERROR();
     if (!a || !a->g || !a->out || !a->workspace || a->n <= 0 || (a->n & 3)) return WJ_ERR_ARG;
-    const int grid = grid_for(a->n / 4, 256, 1024);
+    int grid = grid_for(a->n / 4, 256, 1024);
+    if (a->workgroups > 0 && a->workgroups < grid) grid = a->workgroups;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, STREAM, a->g, a->workspace, (long)a->n);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, STREAM, (const float*)a->workspace, a->out, grid);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, STREAM, (const float*)a->workspace, a->out, grid, a->accumulate);
     WJ_CHECK_LAUNCH();
     return WJ_OK;
 }

@@ -358,8 +358,11 @@ class JepaEngine:
         # batched transpose, wj_transpose_bf16): the persistent eight-phase kernel instead of the col-form 256 x 128 schedule.
         # WJ_WT_DGRAD=0 keeps the col-form dgrads (A/B runs).
         self.wt_dgrad = _os.environ.get("WJ_WT_DGRAD", "1") != "0"
-        # K-split pairs for the student's 117-tile GEMMs (WJ_PAIR_SPLIT=0: off): scratch handed to the main-stream launches of that stack
-        self.pair_split = _os.environ.get("WJ_PAIR_SPLIT", "1") != "0"
+        # K-split pairs for the student's 117-tile GEMMs (scratch handed to the main-stream launches of that stack).  Round 6: OFF by default
+        # -- on the two-stream step they move nothing (46.85 / 46.87 ms in round 5, 46.09 with / 46.02 without in round 6, interleaved on one
+        # box) while costing 30 MB of partial sums per launch (traffic 1.31 x algorithmic) and a spin-wait between workgroups; a one-stream
+        # host gains 0.3 ms with WJ_PAIR_SPLIT=1 (or wj_gemm_args.workspace in its own calls).
+        self.pair_split = (_os.environ.get("WJ_PAIR_SPLIT", "0") == "1") if self.use_side else (_os.environ.get("WJ_PAIR_SPLIT", "1") != "0")
         self.pair_ws = None
         self._conv_w_fresh = False
         self.defer_folds = _os.environ.get("WJ_DEFER_FOLDS", "1") != "0"
@@ -375,6 +378,9 @@ class JepaEngine:
         self.ln_lean = {t.strip() for t in lean.replace("+", ",").split(",") if t.strip() and t.strip() != "0"} if self.use_side else set()
         self.ln_lean_wgs = int(_os.environ.get("WJ_LN_LEAN_WGS", "256"))
         self._lean_now = False                 # set inside the training forward only: inference runs one stream, nothing to stream under
+        # WJ_CONV_SPLIT=1: conv layers 1.. as two half-batch chains on two streams (see _frontend)
+        self.conv_split = _os.environ.get("WJ_CONV_SPLIT", "0") == "1"
+        self.aux = torch.cuda.Stream(device=self.dev) if (self.conv_split and self.use_side) else None
         self._folds = []
         self._bind_params()
         self._bind_wt()
@@ -998,12 +1004,36 @@ class JepaEngine:
                           yx=self.gn_yx[c0:] if grad else None, x1=self.gn_x1[c0:] if grad else None,
                           audio_clip_stride=S * c.in_channels * c.n_samples if S > 1 else 0)
         self._conv_weight_layouts()
-        for l in range(1, len(c.conv_spec)):
+
+        def conv_layer(l: int, si: int, c0: int, nclips: int) -> None:
             _, k, s = c.conv_spec[l]
-            for si, c0, nclips in self._stack_groups():
-                ops.gemm(self.post_ptr[l - 1] + c0 * self.P[l - 1] * C * 2, self._conv_w[f"{si}:wp{l}"], self.pre_ptr[l] + c0 * self.P[l] * C * 2,
-                         C2=self.post_ptr[l] + c0 * self.P[l] * C * 2, M=nclips * self.P[l], N=C, K=k * C, lda=s * C, ldb=k * C, ldc=C,
-                         epilogue=ops.EPI_CONV_GELU, seg_rows=self.P[l], seg_valid=self.L[l])
+            ops.gemm(self.post_ptr[l - 1] + c0 * self.P[l - 1] * C * 2, self._conv_w[f"{si}:wp{l}"], self.pre_ptr[l] + c0 * self.P[l] * C * 2,
+                     C2=self.post_ptr[l] + c0 * self.P[l] * C * 2, M=nclips * self.P[l], N=C, K=k * C, lda=s * C, ldb=k * C, ldc=C,
+                     epilogue=ops.EPI_CONV_GELU, seg_rows=self.P[l], seg_valid=self.L[l])
+
+        groups = self._stack_groups()
+        if self.conv_split and self.use_side and self._lean_now and len(groups) == 1 and groups[0][2] >= 16:
+            # The conv stack as TWO independent chains (the clips' halves) on two streams.  Every layer is a persistent launch whose last
+            # round of work items leaves most CUs idle (L3-L5: 6.3 / 3.1 / 1.6 rounds of 256 workgroups), and at this point of the step no
+            # other stream has matrix work to put there.  Two chains are work-conserving between them: the workgroups of one chain's layer
+            # start on the CUs the other chain's layer has already left.
+            si, c0, n = groups[0]
+            h0 = n // 2
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.aux.wait_event(ev)
+            for l in range(1, len(c.conv_spec)):
+                conv_layer(l, si, c0, h0)
+                with torch.cuda.stream(self.aux):
+                    conv_layer(l, si, c0 + h0, n - h0)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.aux)
+            main.wait_event(ev2)
+        else:
+            for l in range(1, len(c.conv_spec)):
+                for si, c0, nclips in groups:
+                    conv_layer(l, si, c0, nclips)
         M, T = self.M, self.T
         ops.layernorm_fwd(self.post_ptr[-1], f.ptr32("feature_norms.weight"), f.ptr32("feature_norms.bias"), M=M, D=C,
                           eps=c.norm_eps, y_bf16=self.fn_b, mean=self.fn_mean, rstd=self.fn_rstd, x_is_bf16=True,
@@ -1194,7 +1224,9 @@ class JepaEngine:
         c, f, plan = self.cfg, self.flat, self.plan
         N, M, Mp, T, G, C = self.N, self.M, self.Mp, self.T, self.G, self.C
         De, Dd = c.d_enc, c.d_dec
-        f.g32.zero_()
+        if not getattr(f, "g_clean", False):      # (FusedAdamW.fuse_zero_grad: the last update left the buffer clear)
+            f.g32.zero_()
+        f.g_clean = False
         self.refresh_wt()               # (already done beside the forward; a no-op then)
         rag = self.ragged_step
         Md, dseq = (plan.n_dec, (plan.dec_off, max(plan.max_dec, 1))) if rag else (Mp, None)

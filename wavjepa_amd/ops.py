@@ -433,14 +433,15 @@ def ema_update(student: Ptr, teacher: Ptr, n: int, r: float, teacher_bf16: Ptr =
     _run("wj_ema_update", "wj_ema_args", stream, student=_p(student), teacher=_p(teacher), teacher_bf16=_p(teacher_bf16), n=n, r=r)
 
 
-def grad_sumsq(g: Ptr, out: Ptr, workspace: Ptr, n: int, stream: Optional[int] = None) -> None:
-    _run("wj_grad_sumsq", "wj_sumsq_args", stream, g=_p(g), out=_p(out), workspace=_p(workspace), n=n)
+def grad_sumsq(g: Ptr, out: Ptr, workspace: Ptr, n: int, accumulate: bool = False, workgroups: int = 0, stream: Optional[int] = None) -> None:
+    _run("wj_grad_sumsq", "wj_sumsq_args", stream, g=_p(g), out=_p(out), workspace=_p(workspace), n=n, accumulate=int(accumulate),
+         workgroups=int(workgroups))
 
 
 def adamw_step(p: Ptr, g: Ptr, m: Ptr, v: Ptr, n: int, *, lr: float, beta1: float, beta2: float, eps: float,
                weight_decay: float, step: int, max_norm: float = 0.0, sumsq: Ptr = None, p_bf16: Ptr = None,
-               grad_scale: float = 1.0, workgroups: int = 0, stream: Optional[int] = None) -> None:
-    _run("wj_adamw_step", "wj_adamw_args", stream, workgroups=int(workgroups), p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p_bf16), sumsq=_p(sumsq),
+               grad_scale: float = 1.0, workgroups: int = 0, zero_grad: bool = False, stream: Optional[int] = None) -> None:
+    _run("wj_adamw_step", "wj_adamw_args", stream, workgroups=int(workgroups), zero_grad=int(zero_grad), p=_p(p), g=_p(g), m=_p(m), v=_p(v), p_bf16=_p(p_bf16), sumsq=_p(sumsq),
          n=n, lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, bc1=1.0 - beta1 ** step,
          bc2=1.0 - beta2 ** step, max_norm=max_norm, grad_scale=grad_scale)
 
