@@ -5,7 +5,7 @@
  * wavjepa_amd/lib/libwavjepa_hip_lab.so) additionally
  *   * export the entries below (time stamps of the persistent GEMM; the all-reduce footprint rehearsal),
  *   * honour the result- or schedule-changing diagnostics of csrc/: WJ_PERSIST_DIAG_NOSTORE, WJ_PERSIST_STAMPS, WJ_PERSIST_ACTIVE,
- *     WJ_PERSIST_STAGGER_US / _EPI, WJ_PERSIST_HALF, WJ_PERSIST_WBLOCK, WJ_PERSIST_MIN_TILES, WJ_GEMM_VARIANT, WJ_PAIR_MIN_K, WJ_WGRAD_384,
+ *     WJ_PERSIST_STAGGER_US / _EPI, WJ_PERSIST_HALF, WJ_PERSIST_WBLOCK, WJ_PERSIST_MIN_TILES, WJ_GEMM_VARIANT, WJ_GEMM_PANEL, WJ_PAIR_MIN_K, WJ_WGRAD_384,
  *     WJ_ATTN_BWD_FRAG, WJ_CONV0_STATS_TCS, WJ_CONV0_APPLY_MFMA, WJ_CONV0_APPLY_OCC, WJ_LN_BWD_ONE_PASS_ROWS
  *     (in the release build each of them is compiled to its default: csrc/common.h wj_lab_env_int).
  * tools/ and the tests that rehearse or dissect a kernel load this library (wavjepa_amd._abi.load_lab(), or WAVJEPA_HIP_LIB=<path>). */

@@ -237,6 +237,70 @@ def test_gemm_persistent_half_width_items_and_fewer_workgroups(ops, M, N, K, cus
     assert ops.gemm_set_persist_cus(0) == 32                 # the process default is untouched
 
 
+@pytest.mark.parametrize("M,K,cus,with_bias", [(33100, 384, 32, True),      # 259 panels, the last one shifted inwards; 6 K tiles
+                                                (40000, 1152, 28, True),     # fewer resident workgroups per XCD (the data-parallel default)
+                                                (87421, 1536, 32, False),    # the predictor's linear2 / linear1-dgrad at full size
+                                                (5003, 256, 32, True),       # fewer panels (40) than workgroups; the shortest K (4 K tiles)
+                                                (128, 768, 32, False),       # one panel
+                                                (20001, 384, 5, True)])      # every workgroup walks many panels
+def test_gemm_row_panel_schedule_for_thin_outputs(ops, M, K, cus, with_bias):
+    """Variant 5 (csrc/gemm_panel.hip): N = 384 as full-row work items of 128 rows x 384 columns, A staged four K tiles ahead by waves of its
+    own (the predictor's out_proj / linear2 / dgrads into d = 384; autograd of reference jepa.py:129-131,422-440).  On NaN-filled outputs:
+    against fp32 torch math, BIT-IDENTICAL to the one-tile eight-phase kernel (same k order, bias added last), to itself across launches
+    and across the number of resident workgroups per XCD."""
+    N = 384
+    A = rnd(M, K, dtype=torch.bfloat16, seed=61)
+    W = rnd(N, K, scale=0.08, dtype=torch.bfloat16, seed=62)
+    bias = rnd(N, seed=63) if with_bias else None
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias)
+
+    def run(variant, n_cus=None):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        ops.gemm(A, W, C, schedule=variant, persist_cus=n_cus, **kw)
+        torch.cuda.synchronize()
+        return C
+
+    C5 = run(5, cus)
+    assert not bool(torch.isnan(C5.float()).any())
+    ref = A.float() @ W.float().t() + (bias if with_bias else 0.0)
+    assert relerr(C5.float(), ref) < 4e-3
+    C3 = run(3)
+    assert torch.equal(C5.view(torch.int16), C3.view(torch.int16))
+    for n_cus in (cus, 32, 17):
+        assert torch.equal(run(5, n_cus).view(torch.int16), C5.view(torch.int16)), n_cus
+    # the automatic choice takes it where the rows fill the chip, and keeps the other schedules elsewhere
+    Ca = run(-1)
+    assert relerr(Ca.float(), ref) < 4e-3
+    # strided operands (a column block of a wider activation, output into a column block of a wider buffer)
+    if M <= 40000:
+        Abig = rnd(M, K + 128, dtype=torch.bfloat16, seed=64)
+        Cbig = torch.full((M, N + 256), float("nan"), dtype=torch.bfloat16, device=dev())
+        ops.gemm(Abig, W, Cbig, M=M, N=N, K=K, lda=K + 128, ldb=K, ldc=N + 256, bias=bias, schedule=5)
+        torch.cuda.synchronize()
+        want = Abig[:, :K].float() @ W.float().t() + (bias if with_bias else 0.0)
+        assert relerr(Cbig[:, :N].float(), want) < 4e-3 and bool(torch.isnan(Cbig[:, N:].float()).all())
+
+
+def test_gemm_row_panel_repeated_launches_are_bit_identical(ops):
+    """60 launches of the row-panel kernel into NaN-filled outputs (two streams alternating): every one gives the first one's bits."""
+    M, N, K = 87000, 384, 1152
+    A = rnd(M, K, dtype=torch.bfloat16, seed=65)
+    W = rnd(N, K, scale=0.08, dtype=torch.bfloat16, seed=66)
+    outs = [torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev()) for _ in range(4)]
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(A, W, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, schedule=5)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(60):
+        with torch.cuda.stream(streams[rep & 1]):
+            outs[rep & 3].fill_(float("nan"))
+            ops.gemm(A, W, outs[rep & 3], M=M, N=N, K=K, lda=K, ldb=K, ldc=N, schedule=5)
+        if rep % 4 == 3:
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o.view(torch.int16), ref.view(torch.int16)), rep
+
+
 @pytest.mark.parametrize("M,N,K", [(33001, 1536, 384), (20000, 640, 256), (9907, 3072, 768)])
 def test_gemm_persistent_mul_gelu_grad_with_column_sums(ops, M, N, K):
     """The backward through linear2 + GELU as a row-form GEMM against W^T on the persistent kernel (reference: autograd of

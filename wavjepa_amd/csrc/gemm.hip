@@ -1291,16 +1291,27 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 //   3 = 256x256x64 tile, eight-phase     : row-form operands, K % 128 == 0 (+10..15 % over variant 2 at K = 768, +35 % at 8192^3)
 //   4 = variant 3's loop, persistent     : >= 256 work items; forward epilogues, plain BF16 and MUL_GELU_GRAD (+ column sums) for the
 //                                          row-form dgrads against W^T shadows (csrc/gemm_persist.hip)
+//   5 = row panels, 128 x 384 items      : N = 384, row-form operands, plain BF16 (csrc/gemm_panel.hip)
 // wj_gemm_args.schedule = 1 + v forces variant v for that call (tests, tools/gemm_check.py; 1-3 need N % 256 == 0 to avoid wasted columns
 // but stay correct; a variant that cannot run a shape falls back to 3, then 0); the lab build also honours WJ_GEMM_VARIANT=v for calls
 // that leave the field 0.  The library keeps no selection state.
+// lab build: WJ_GEMM_PANEL=0 keeps the N = 384 shapes on the persistent 256 x 256 kernel (A/B runs)
+bool panel_auto() {
+    static const int on = wj_lab_env_int("WJ_GEMM_PANEL", 1);
+    return on != 0;
+}
+
 int pick_variant(const wj_gemm_args* a) {
     static const int env_forced = wj_lab_env_int("WJ_GEMM_VARIANT", -1);
     const int forced = a->schedule > 0 ? a->schedule - 1 : env_forced;
     const bool ep_ok = !a->a_trans && !a->b_trans && a->K % 128 == 0 && a->split_k <= 1;   // eight-phase schedule (variant 3)
+    if (forced == 5) return wj_gemm_panel_eligible(a) ? 5 : (ep_ok ? 3 : 0);
     if (forced == 4) return wj_gemm_persist_eligible(a) ? 4 : (ep_ok ? 3 : 0);
     if (forced == 3) return ep_ok ? 3 : 0;
     if (forced >= 0 && forced <= 2) return forced;
+    // row panels (csrc/gemm_panel.hip): thin outputs (N = 384) with enough rows to fill the chip -- the predictor's out_proj / linear2 and
+    // its dgrads into d = 384; full-row work items, A staged four K tiles ahead by waves of its own
+    if (forced < 0 && panel_auto() && wj_gemm_panel_eligible(a) && a->M >= 128 * 256) return 5;
     // persistent eight-phase (csrc/gemm_persist.hip): the same K loop without the per-tile prologue / LDS-staged epilogue / dispatch gap
     // (its edge tiles are shifted inwards: a last tile column narrower than half a tile is mostly duplicate work)
     if (ep_ok && (a->N % 256 == 0 || a->N % 256 >= 128) && wj_gemm_persist_eligible(a)) return 4;
@@ -1316,6 +1327,13 @@ int pick_variant(const wj_gemm_args* a) {
 template <bool AT, bool BT, int EPI>
 int launch_bn(const wj_gemm_args* a, hipStream_t s) {
     int v = pick_variant(a);
+    if (v == 5) {
+        if constexpr (!AT && !BT && EPI == WJ_EPI_BF16) {
+            const int rc = wj_gemm_panel_launch(a, s);
+            if (rc != WJ_ERR_UNSUPPORTED) return rc;
+        }
+        v = wj_gemm_persist_eligible(a) ? 4 : 3;
+    }
     if (v == 4) {
         const int rc = wj_gemm_persist_launch(a, s);
         if (rc != WJ_ERR_UNSUPPORTED) return rc;
@@ -1466,7 +1484,7 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD_Z && (!a->aux || !a->rowmap || ((uintptr_t)a->aux & 15))) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
     if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;
-    if (a->schedule < 0 || a->schedule > 5 || a->persist_cus < 0 || a->persist_cus > 32) return WJ_ERR_ARG;
+    if (a->schedule < 0 || a->schedule > 6 || a->persist_cus < 0 || a->persist_cus > 32) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (a->rowmap) {
         // gather forms (sparse conv backward), one instantiation each

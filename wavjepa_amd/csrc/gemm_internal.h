@@ -8,3 +8,7 @@
 bool wj_gemm_persist_eligible(const wj_gemm_args* a);
 // WJ_OK, or WJ_ERR_UNSUPPORTED (not eligible / no scheduling slot left for this stream: the caller takes another variant)
 int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s);
+
+// csrc/gemm_panel.hip: the row-panel schedule for thin outputs (variant 5: N = 384, row-form operands, K % 128 == 0, K >= 256, WJ_EPI_BF16)
+bool wj_gemm_panel_eligible(const wj_gemm_args* a);
+int wj_gemm_panel_launch(const wj_gemm_args* a, hipStream_t s);
