@@ -171,7 +171,7 @@ def gemm_kernel_name(f) -> str:
     return f"gemm_kernel<{'T' if f['a_trans'] else 'N'}{'T' if f['b_trans'] else 'N'},{epi}>"
 
 
-PMC_FILES = ["r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
+PMC_FILES = ["r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
 
 
 def pmc_traffic_path():
@@ -218,11 +218,11 @@ def gemm_class_patterns(name: str):
 
 def committed_rocprof_serial(name: str, workload: str, clips_per_gpu: int):
     """The class's rate in the COMMITTED `rocprofv3 --kernel-trace --stats` summary of this command with the side stream serialised
-    (profiles/r05_serial_meta.json, written by tools/serial_meta.py next to the CSV it describes: that run's own algorithmic flops of the
+    (profiles/r06_serial_meta.json -- or the previous round's --, written by tools/serial_meta.py next to the CSV it describes: that run's own algorithmic flops of the
     class over that run's own kernel time, with its commit and configuration).  Returned only when the committed run had this run's
     workload and clips per GPU -- a cross-check from another box, labelled as such, never a judged metric."""
-    path = os.path.join(ROOT, "profiles", "r05_serial_meta.json")
-    if not os.path.exists(path):
+    path = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r06_serial_meta.json", "r05_serial_meta.json")) if os.path.exists(p)), None)
+    if path is None:
         return None
     meta = json.load(open(path))
     c = meta.get("classes", {}).get(name)

@@ -1187,6 +1187,36 @@ def test_ema_adamw_sumsq_cast(ops):
     assert torch.equal(c, src.to(torch.bfloat16))
 
 
+def test_adamw_fused_zero_grad_and_sumsq_by_sections(ops):
+    """ABI 16: wj_adamw_args.zero_grad clears the gradient behind the read (same update, g == 0 afterwards, also on a capped grid);
+    wj_sumsq_args.accumulate / .workgroups give the squared norm section by section -- the sum of the sections' sums."""
+    n = 4 * 250001
+    g = rnd(n, scale=0.02, seed=182)
+    out = torch.zeros(1, device=dev())
+    ws = torch.empty(1024, device=dev())
+    ops.grad_sumsq(g, out, ws, n)
+    whole = float(out)
+    cuts = [0, 4 * 1000, 4 * 77777, 4 * 200000, n]
+    acc = torch.full((1,), 123.0, device=dev())                     # (overwritten by the first, non-accumulating section)
+    for k, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
+        ops.grad_sumsq(g.data_ptr() + 4 * lo, acc, ws, hi - lo, accumulate=k > 0, workgroups=0 if k % 2 else 37)
+    assert abs(float(acc) - whole) < 2e-6 * whole and abs(whole - float(g.double().pow(2).sum())) < 1e-5 * whole
+    kw = dict(lr=1e-3, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.04, step=1, max_norm=0.5, sumsq=out)
+    res = []
+    for zg, wgs in ((False, 0), (True, 0), (True, 64)):
+        p = rnd(n, seed=183)
+        gg = g.clone()
+        m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+        pb = torch.empty(n, dtype=torch.bfloat16, device=dev())
+        ops.adamw_step(p, gg, m, v, n, p_bf16=pb, zero_grad=zg, workgroups=wgs, **kw)
+        torch.cuda.synchronize()
+        res.append((p, m, v, pb))
+        assert (float(gg.abs().max()) == 0.0) == zg
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
 def test_crop_normalize(ops, golden_dir):
     import os
     fx = dict(np.load(os.path.join(golden_dir, "crops.npz")))

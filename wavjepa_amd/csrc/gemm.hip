@@ -1295,9 +1295,12 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 // wj_gemm_args.schedule = 1 + v forces variant v for that call (tests, tools/gemm_check.py; 1-3 need N % 256 == 0 to avoid wasted columns
 // but stay correct; a variant that cannot run a shape falls back to 3, then 0); the lab build also honours WJ_GEMM_VARIANT=v for calls
 // that leave the field 0.  The library keeps no selection state.
-// lab build: WJ_GEMM_PANEL=0 keeps the N = 384 shapes on the persistent 256 x 256 kernel (A/B runs)
+// The row-panel kernel is NOT picked automatically: on the predictor's shapes it measures what the persistent 256 x 256 kernel measures
+// (cold 51-53 / 109-113 / 142-152 us at K = 384 / 1152 / 1536 either way; the step 46.04 against 45.96 ms interleaved) -- both are bound by
+// the ISSUE of the LDS-DMA instructions, ~65 ns per 1-KB piece and wave (tools/panel_diag.py, DESIGN_EXPERIMENTS.md round 6).  It runs
+// where wj_gemm_args.schedule asks for it; lab build: WJ_GEMM_PANEL=1 picks it for every eligible shape (A/B runs).
 bool panel_auto() {
-    static const int on = wj_lab_env_int("WJ_GEMM_PANEL", 1);
+    static const int on = wj_lab_env_int("WJ_GEMM_PANEL", 0);
     return on != 0;
 }
 

@@ -58,6 +58,7 @@ struct QArgs {
     long ldc_b;
     unsigned lda_b, ldb_b;
     int M, K, nitems, wpx;
+    int diag;                 // lab build (WJ_PANEL_DIAG): 1 = no W pieces, 2 = no A pieces, 4 = no MFMAs, 8 = no fragment reads, 16 = no stores (timing only: wrong results); 32 = K rotation per workgroup (correct results, other summation order)
 };
 
 template <int N>
@@ -89,7 +90,7 @@ template <int SUB, int PB, int PA>
 __device__ __forceinline__ void step(f32x4 (&acc)[4][2 * THIRDS], bf16x8 (&af)[2][4][2], bf16x8 (&bf)[2][2][2], char* smem, const QArgs& a,
                                      Cursor& cur, unsigned& slot_b, unsigned& slot_a, int nk, int n_my, int q0, int cstart,
                                      const unsigned (&voff)[4], const unsigned (&dpiece)[4], unsigned a_rd, unsigned b_rd, bool a_wave,
-                                     int& lag_w, int& lag_a) {
+                                     int& lag_w, int& lag_a, int rot) {
     // ---- wait for the pieces the NEXT step multiplies.  W waves: W step j + 1 (issued three steps ago; two younger steps = 8 instructions
     // may stay in flight).  A waves, in the last step of a K tile only: the A tile of the next K tile (issued four K tiles ago; three
     // younger tiles = 12).  Behind an epilogue its 12 stores are younger than the awaited piece for three steps / three K tiles.
@@ -108,11 +109,15 @@ __device__ __forceinline__ void step(f32x4 (&acc)[4][2 * THIRDS], bf16x8 (&af)[2
     // ---- stage W step j + 4 into the slot step j occupied (its fragments were read during step j - 1), and in the first step of a K
     // tile the A tile four K tiles ahead into the slot whose fragments were read at the end of the previous K tile
     {
-        const char* sb = a.B + (long)(cur.b_sub * 128) * a.ldb_b + (long)cur.b_kt * 128;
+        const int bk = cur.b_kt + rot < nk ? cur.b_kt + rot : cur.b_kt + rot - nk;   // this workgroup's K order starts at K tile `rot`
+        const char* sb = a.B + (long)(cur.b_sub * 128) * a.ldb_b + (long)bk * 128;
         const unsigned dst = B_RING + slot_b * SLOT;
         if (!a_wave) {
+            // (lab build, timing diagnostics: the pieces are re-read from ONE line so that the vmcnt arithmetic stays what it is)
+            const char* src = (WJ_LAB_BUILD && (a.diag & 1)) ? a.B : sb;
+            const unsigned mask = (WJ_LAB_BUILD && (a.diag & 1)) ? 0u : ~0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dma(voff[u], sb, dpiece[u] + dst);
+            for (int u = 0; u < 4; ++u) dma(voff[u] & mask, src, dpiece[u] + dst);
         }
         slot_b = (slot_b + 1) & 3;
         if (++cur.b_sub == THIRDS) { cur.b_sub = 0; if (++cur.b_kt == nk) cur.b_kt = 0; }
@@ -120,18 +125,21 @@ __device__ __forceinline__ void step(f32x4 (&acc)[4][2 * THIRDS], bf16x8 (&af)[2
     if constexpr (SUB == 0) {
         const int it = cur.a_it < n_my ? cur.a_it : n_my - 1;                // past the last item: the last panel again (never multiplied)
         const int m0 = min((cstart + q0 + it * a.wpx) * 128, a.M - 128);
-        const char* sa = a.A + (long)m0 * a.lda_b + (long)cur.a_kt * 128;
+        const int ak = cur.a_kt + rot < nk ? cur.a_kt + rot : cur.a_kt + rot - nk;
+        const char* sa = a.A + (long)m0 * a.lda_b + (long)ak * 128;
         const unsigned dst = A_RING + slot_a * SLOT;
         if (a_wave) {
+            const char* src = (WJ_LAB_BUILD && (a.diag & 2)) ? a.A : sa;
+            const unsigned mask = (WJ_LAB_BUILD && (a.diag & 2)) ? 0u : ~0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dma(voff[u], sa, dpiece[u] + dst);
+            for (int u = 0; u < 4; ++u) dma(voff[u] & mask, src, dpiece[u] + dst);
         }
         slot_a = (slot_a + 1) & 3;
         if (++cur.a_kt == nk) { cur.a_kt = 0; ++cur.a_it; }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- fragments of step j + 1 into the other register set: W (slot_b now names step j + 1's slot) ...
-    {
+    if (!(WJ_LAB_BUILD && (a.diag & 8))) {
         const char* bs = smem + B_RING + slot_b * SLOT;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -140,7 +148,7 @@ __device__ __forceinline__ void step(f32x4 (&acc)[4][2 * THIRDS], bf16x8 (&af)[2
         }
     }
     // ... and, in the last step of a K tile, the A fragments of the next K tile (slot_a, advanced in the K tile's first step, names the NEXT K tile's slot)
-    if constexpr (SUB == THIRDS - 1) {
+    if (SUB == THIRDS - 1 && !(WJ_LAB_BUILD && (a.diag & 8))) {
         const char* as = smem + A_RING + slot_a * SLOT;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -150,6 +158,7 @@ __device__ __forceinline__ void step(f32x4 (&acc)[4][2 * THIRDS], bf16x8 (&af)[2
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- multiply step j from the registers the previous step filled
+    if (WJ_LAB_BUILD && (a.diag & 4)) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -188,7 +197,9 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][2 * THIRDS], char* smem
             __builtin_amdgcn_wave_barrier();
             const u32x4 o = *reinterpret_cast<const u32x4*>(rd);
             __builtin_amdgcn_wave_barrier();
-            __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(c0 + (long)(mi * 16) * a.ldc_b + (long)(t * 128) * 2));
+            // (lab build, diag 16: the stores go to ONE line per lane group -- same count, no write traffic)
+            char* dst = (WJ_LAB_BUILD && (a.diag & 16)) ? a.C + (lane & 7) * 16 : c0 + (long)(mi * 16) * a.ldc_b + (long)(t * 128) * 2;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
         }
     }
 }
@@ -230,6 +241,11 @@ __global__ __launch_bounds__(NT, 1) void gemm_panel_kernel(QArgs a) {
     const unsigned a_rd = (unsigned)((wm * 64 + i) * 128) + sw;
     const unsigned b_rd = (unsigned)((wn * 32 + i) * 128) + sw;
 
+    // K rotation (lab build, WJ_PANEL_DIAG bit 32): workgroup w walks the K tiles of every item from tile rot(w) round to rot(w) - 1, so
+    // that at any instant the chip's workgroups read DIFFERENT 128-byte columns of their A rows (all of them start together and move at
+    // the same pace: unrotated, every row piece in flight has the same address bits 7-10 -- the same few memory channels)
+    const int rot = (WJ_LAB_BUILD && (a.diag & 32)) ? (q0 + 3 * xl) % nk : 0;
+    auto phys = [&](int kt) { return kt + rot < nk ? kt + rot : kt + rot - nk; };
     // ---- prologue: A tiles 0-3 of the first item (nk >= 4) by the A waves, W steps 0-3 by the W waves
     Cursor cur;
     cur.a_it = 0; cur.a_kt = 4; cur.b_kt = 1; cur.b_sub = 1;          // the cursors behind the prologue: A tile 4, W step 4 = (K tile 1, third 1)
@@ -239,12 +255,12 @@ __global__ __launch_bounds__(NT, 1) void gemm_panel_kernel(QArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (a_wave) {
-                const char* sa = a.A + (long)m0 * a.lda_b + (long)k * 128;
+                const char* sa = a.A + (long)m0 * a.lda_b + (long)phys(k) * 128;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dma(voff[u], sa, dpiece[u] + A_RING + k * SLOT);
             } else {
                 const int kt = k / THIRDS, sub = k - kt * THIRDS;       // W step k
-                const char* sb = a.B + (long)(sub * 128) * a.ldb_b + (long)kt * 128;
+                const char* sb = a.B + (long)(sub * 128) * a.ldb_b + (long)phys(kt) * 128;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dma(voff[u], sb, dpiece[u] + B_RING + k * SLOT);
             }
@@ -278,12 +294,12 @@ __global__ __launch_bounds__(NT, 1) void gemm_panel_kernel(QArgs a) {
 #pragma unroll
             for (int c = 0; c < 2 * THIRDS; ++c) acc[mi][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; kt += 2) {
-            step<0, 0, 0>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a);
-            step<1, 1, 0>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a);
-            step<2, 0, 0>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a);
-            step<0, 1, 1>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a);
-            step<1, 0, 1>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a);
-            step<2, 1, 1>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a);
+            step<0, 0, 0>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a, rot);
+            step<1, 1, 0>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a, rot);
+            step<2, 0, 0>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a, rot);
+            step<0, 1, 1>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a, rot);
+            step<1, 0, 1>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a, rot);
+            step<2, 1, 1>(acc, af, bf, smem, a, cur, slot_b, slot_a, nk, n_my, q0, cstart, voff, dpiece, a_rd, b_rd, a_wave, lag_w, lag_a, rot);
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // MFMA results of the last step -> VALU readers behind the loop branch
@@ -317,6 +333,7 @@ int wj_gemm_panel_launch(const wj_gemm_args* a, hipStream_t s) {
     p.M = a->M; p.K = a->K;
     p.nitems = (a->M + 127) / 128;
     p.wpx = a->persist_cus > 0 ? (a->persist_cus > 32 ? 32 : a->persist_cus) : 32;
+    p.diag = wj_lab_env_int("WJ_PANEL_DIAG", 0);              // (read per launch in the lab build: a timing tool sweeps it)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return WJ_ERR_UNSUPPORTED;
     static std::atomic<bool> lds_ok[32];

@@ -378,9 +378,6 @@ class JepaEngine:
         self.ln_lean = {t.strip() for t in lean.replace("+", ",").split(",") if t.strip() and t.strip() != "0"} if self.use_side else set()
         self.ln_lean_wgs = int(_os.environ.get("WJ_LN_LEAN_WGS", "256"))
         self._lean_now = False                 # set inside the training forward only: inference runs one stream, nothing to stream under
-        # WJ_CONV_SPLIT=1: conv layers 1.. as two half-batch chains on two streams (see _frontend)
-        self.conv_split = _os.environ.get("WJ_CONV_SPLIT", "0") == "1"
-        self.aux = torch.cuda.Stream(device=self.dev) if (self.conv_split and self.use_side) else None
         self._folds = []
         self._bind_params()
         self._bind_wt()
@@ -1011,29 +1008,9 @@ class JepaEngine:
                      C2=self.post_ptr[l] + c0 * self.P[l] * C * 2, M=nclips * self.P[l], N=C, K=k * C, lda=s * C, ldb=k * C, ldc=C,
                      epilogue=ops.EPI_CONV_GELU, seg_rows=self.P[l], seg_valid=self.L[l])
 
-        groups = self._stack_groups()
-        if self.conv_split and self.use_side and self._lean_now and len(groups) == 1 and groups[0][2] >= 16:
-            # The conv stack as TWO independent chains (the clips' halves) on two streams.  Every layer is a persistent launch whose last
-            # round of work items leaves most CUs idle (L3-L5: 6.3 / 3.1 / 1.6 rounds of 256 workgroups), and at this point of the step no
-            # other stream has matrix work to put there.  Two chains are work-conserving between them: the workgroups of one chain's layer
-            # start on the CUs the other chain's layer has already left.
-            si, c0, n = groups[0]
-            h0 = n // 2
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.aux.wait_event(ev)
-            for l in range(1, len(c.conv_spec)):
-                conv_layer(l, si, c0, h0)
-                with torch.cuda.stream(self.aux):
-                    conv_layer(l, si, c0 + h0, n - h0)
-            ev2 = torch.cuda.Event()
-            ev2.record(self.aux)
-            main.wait_event(ev2)
-        else:
-            for l in range(1, len(c.conv_spec)):
-                for si, c0, nclips in groups:
-                    conv_layer(l, si, c0, nclips)
+        for l in range(1, len(c.conv_spec)):
+            for si, c0, nclips in self._stack_groups():
+                conv_layer(l, si, c0, nclips)
         M, T = self.M, self.T
         ops.layernorm_fwd(self.post_ptr[-1], f.ptr32("feature_norms.weight"), f.ptr32("feature_norms.bias"), M=M, D=C,
                           eps=c.norm_eps, y_bf16=self.fn_b, mean=self.fn_mean, rstd=self.fn_rstd, x_is_bf16=True,

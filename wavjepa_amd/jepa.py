@@ -125,7 +125,6 @@ _ADAMW_SIDE = os.environ.get("WJ_ADAMW_SIDE", "1") != "0"
 # (a full grid of 8192: 45.68 ms/step, 1024: 45.64, 512: 45.48, 256: 45.40, interleaved on one box; 128 / 192 / 384 within 0.1 of 256)
 _ADAMW_SIDE_WGS = int(os.environ.get("WJ_ADAMW_SIDE_WGS", "256"))
 _ADAMW_ZERO_GRAD = os.environ.get("WJ_ADAMW_ZERO_GRAD", "1") != "0"
-_SUMSQ_SECTIONS = os.environ.get("WJ_SUMSQ_SECTIONS", "1") != "0"
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -141,8 +140,6 @@ class FusedAdamW(torch.optim.Optimizer):
         self._t = 0
         self._sumsq = None
         self._ws = None
-        self._ranges = None
-        self._sections_seen = set()
         # overlap_next_forward (set by the training loop, trainer.StepRunner; WJ_ADAMW_SIDE=0 keeps it off): only the conv extractor, the
         # feature norm and the post-extraction mapper are updated on the compute stream; the transformer stacks (99 % of the parameters,
         # ~0.65 ms of streaming) go to the engine's side stream, where they run beside the NEXT step's crop / conv0 / conv stack -- matrix-
@@ -157,44 +154,11 @@ class FusedAdamW(torch.optim.Optimizer):
         # (wj_adamw_args.zero_grad), so the next backward starts from a clean flat buffer without its own 444-MB fill on the critical path.
         # p.grad then reads 0 after step() -- what zero_grad() leaves; a caller that inspects gradients after step() keeps it off.
         self.fuse_zero_grad = False
-        # sectioned_sumsq (training loop, one rank; WJ_SUMSQ_SECTIONS=0 keeps it off): the global gradient norm is accumulated section by
-        # section from the backward's hooks (engine.backward: on_grads_ready), capped at one workgroup per CU on the side stream, instead
-        # of one pass over all 111 M gradients between the backward and the update
-        self.sectioned_sumsq = False
-        self._sections_done = False
 
     def _ensure_scratch(self, flat) -> None:
         if self._sumsq is None:
             self._sumsq = torch.zeros(1, dtype=torch.float32, device=flat.device)
             self._ws = torch.empty(1024, dtype=torch.float32, device=flat.device)
-            self._ws_side = torch.empty(1024, dtype=torch.float32, device=flat.device)
-
-    def section_hook(self, tag: str) -> None:
-        """engine.backward's on_grads_ready (single rank): the squared norm of the section of the flat gradient buffer that has just become
-        final, added to the running sum.  Called in stream order (side stream for every tag but "front")."""
-        if not (self.sectioned_sumsq and self.max_grad_norm > 0):
-            return
-        m = self._module
-        flat = m._flat
-        self._ensure_scratch(flat)
-        if self._ranges is None:
-            from .ddp import section_ranges
-            self._ranges = section_ranges(flat, m.encoder.num_layers, 3)
-        if tag not in self._ranges:           # the engine reports "enc:<i>" per layer; a chunk of three is final with its LOWEST layer
-            return
-        first = not self._sections_seen
-        for lo, hi in self._ranges[tag]:
-            ws = self._ws if tag == "front" else self._ws_side
-            ops.grad_sumsq(flat.g32.data_ptr() + 4 * lo, self._sumsq, ws, hi - lo, accumulate=not first,
-                           workgroups=0 if tag == "front" else _ADAMW_SIDE_WGS)
-            first = False
-        self._sections_seen.add(tag)
-        if self._sections_seen == set(self._ranges):
-            self._sections_done = True
-
-    def begin_backward(self) -> None:
-        self._sections_seen = set()
-        self._sections_done = False
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -209,10 +173,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._ensure_scratch(flat)
         g = self.param_groups[0]
         self._t += 1
-        if self.max_grad_norm > 0 and not self._sections_done:
+        if self.max_grad_norm > 0:
             ops.grad_sumsq(flat.g32, self._sumsq, self._ws, flat.n)
-        self._sections_done = False
-        self._sections_seen = set()
         zg = bool(self.fuse_zero_grad) and _ADAMW_ZERO_GRAD
         kw = dict(lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._t,
                   max_norm=self.max_grad_norm, sumsq=self._sumsq if self.max_grad_norm > 0 else None)

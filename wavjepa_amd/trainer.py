@@ -99,18 +99,11 @@ class StepRunner:
             # (JEPA only: its engine's forward knows where to wait.)  This loop reads parameters only through the engine / state_dict, which wait
             self.optimizer.overlap_next_forward = True
             self.optimizer.fuse_zero_grad = True        # (this loop never reads p.grad behind step())
-            from .jepa import _SUMSQ_SECTIONS
-            if model._grads_ready_hook is None and _SUMSQ_SECTIONS and model._engine.use_side:
-                # one rank: the backward's section hooks are free -- the gradient norm is accumulated section by section beside the backward
-                self.optimizer.sectioned_sumsq = True
-                model._grads_ready_hook = self.optimizer.section_hook
 
     def step(self, raw_batch, batch_idx: int) -> Dict[str, Any]:
         m = self.model
         batch = m.on_after_batch_transfer(raw_batch, 0)     # crops + normalise + bf16 on the device
         out = m.training_step(batch, batch_idx)             # forward + EMA of the teacher
-        if getattr(self.optimizer, "sectioned_sumsq", False):
-            self.optimizer.begin_backward()
         out["loss"].backward()                              # engine backward; buckets all-reduce as they complete
         if not self.sectioned:
             self.reducer.reduce_all()
