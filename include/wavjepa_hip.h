@@ -73,7 +73,9 @@ typedef struct {
     int32_t seg_rows, seg_valid;
     float alpha;
     void* workspace;         /* optional scratch, wj_workspace_bytes("wj_gemm_bf16", args) bytes, ZERO-FILLED ONCE by the caller and then */
-    int64_t workspace_bytes; /* left to the library (one per stream that launches GEMMs concurrently).  With it, row-form WJ_EPI_BF16
+    int64_t workspace_bytes; /* left to the library.  ONE pair-capable launch in flight per device: the two workgroups of a tile wait for each
+                                other's flag, so both roles must become resident -- two such launches at once can fill an XCD with first
+                                halves only (the engine hands the scratch to its main-stream launches only).  With it, row-form WJ_EPI_BF16
                                 problems of 33-128 output tiles and K >= 1536 (the ragged student's N = 768 linears and dgrads: 117 tiles
                                 for 256 CUs) run as K-split PAIRS: two workgroups per tile, half of K each, fp32 partial sums exchanged
                                 through the scratch (csrc/gemm.hip).  NULL / too small: one workgroup per tile, as before. */
@@ -89,6 +91,11 @@ typedef struct {
                                 persistent GEMM of the backward is resident -- a 150-KiB-LDS workgroup on every CU leaves them none. */
 } wj_gemm_args;
 int wj_gemm_bf16(const wj_gemm_args*, void* stream);
+/* Optional: tell the library that `stream` is being retired (call before hipStreamDestroy, with none of its GEMMs in flight).  The persistent
+ * schedule keeps one set of tile counters per launching stream (64 sets; sets of idle streams are recycled least-recently-used anyway, which
+ * asks the runtime whether the old owner is idle): a released set is reused without any query of a handle that may no longer exist.  Host
+ * call: no stream argument beyond the handle, returns WJ_OK also for a stream the library has never seen. */
+int wj_gemm_release_stream(void* stream);
 /* ------------------------------------------------------------------------------------------------------------
  * MX fp8 GEMM (BASELINE config 5; build-defined numerics, the reference has no fp8): C[M,N] = A . B^T with A [M][K], B [N][K] OCP
  * e4m3 bytes (K contiguous, lda / ldb in BYTES, multiples of 16) and one E8M0 scale per 32 consecutive k of every row:

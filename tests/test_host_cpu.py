@@ -264,6 +264,14 @@ def test_size_large_layout_and_gradient_buckets_at_24_layers(golden_dir):
     assert not lo <= by["encoder.layers.20.linear2.bias"].offset < hi
 
 
+def test_gemm_release_stream_is_a_host_call():
+    """wj_gemm_release_stream: releasing a stream the library has never seen is a no-op that succeeds (no GPU needed: the counter-set
+    table is host state)."""
+    from wavjepa_amd import ops
+    ops.gemm_release_stream(0)
+    ops.gemm_release_stream(0x1234)
+
+
 def test_workspace_query():
     """wj_workspace_bytes: the caller sizes every scratch buffer from the library (no compute, runs without a GPU)."""
     from wavjepa_amd import ops

@@ -1460,6 +1460,17 @@ def test_gemm_persistent_counter_slots_are_recycled(ops):
         assert not bool(torch.isnan(ref.float()).any()) and relerr(ref.float(), A.float() @ W.float().t()) < 4e-3
         for C in outs[1:]:
             assert torch.equal(C.view(torch.int16), ref.view(torch.int16))
+        # streams handed back explicitly (wj_gemm_release_stream, before they are destroyed): their counter sets serve the next newcomers
+        for st in streams[-8:]:
+            st.synchronize()
+            ops.gemm_release_stream(st.cuda_stream)
+        fresh = [torch.cuda.Stream() for _ in range(8)]
+        for st in fresh:
+            C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+            with torch.cuda.stream(st):
+                ops.gemm(A, W, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+            st.synchronize()
+            assert torch.equal(C.view(torch.int16), ref.view(torch.int16))
     finally:
         ops.gemm_set_variant(prev)
 

@@ -94,7 +94,7 @@ def _make_struct(name: str, fields):
 STRUCTS = {name: _make_struct(name, fields) for name, fields in _STRUCT_FIELDS.items()}
 LAB_STRUCTS = {name: _make_struct(name, fields) for name, fields in _LAB_STRUCT_FIELDS.items()}
 _NO_STREAM_FUNCS = {"wj_abi_version": [], "wj_device_count": [], "wj_struct_size": [ctypes.c_char_p],
-                    "wj_debug_persist_stamps": [ctypes.c_void_p, ctypes.c_int],
+                    "wj_debug_persist_stamps": [ctypes.c_void_p, ctypes.c_int], "wj_gemm_release_stream": [ctypes.c_void_p],
                     "wj_ln_bwd_partial_rows": [ctypes.c_int, ctypes.c_int], "wj_scatter_fill_bwd_partial_rows": [ctypes.c_int, ctypes.c_int],
                     "wj_rccl_unique_id": [ctypes.c_void_p],
                     "wj_rccl_bucket_allreduce_init": [ctypes.c_void_p], "wj_rccl_bucket_allreduce_finalize": []}

@@ -738,8 +738,10 @@ struct SlotTable {
     std::unordered_map<hipStream_t, int> slots;
     hipStream_t owner[SLOTS] = {};
     unsigned long long last_use[SLOTS] = {};      // launch sequence number of the slot's latest launch (LRU order)
+    bool released[SLOTS] = {};                    // handed back by wj_gemm_release_stream: free without asking the runtime about its old owner
     unsigned long long seq = 0;
     unsigned* base[32] = {};      // per device: g_sched_ctr is a __device__ symbol, every device has its own copy
+    int used = 0;                 // counter sets handed out so far (never-used ones first, then released ones, then idle ones LRU)
 };
 SlotTable& table() {
     static SlotTable t;
@@ -874,6 +876,20 @@ extern "C" int wj_debug_persist_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+// The caller retires a stream: its counter set goes back to the pool at once (no query of a handle that may be dead by the time another
+// stream needs a set).  Safe only when no persistent GEMM of that stream is in flight -- the caller's statement, as destroying the stream is.
+extern "C" int wj_gemm_release_stream(void* stream) {
+    SlotTable& T = table();
+    std::lock_guard<std::mutex> lk(T.mu);
+    auto it = T.slots.find((hipStream_t)stream);
+    if (it == T.slots.end()) return WJ_OK;                 // never launched a persistent GEMM: nothing to release
+    T.owner[it->second] = nullptr;
+    T.last_use[it->second] = 0;                            // first in line for the next newcomer
+    T.released[it->second] = true;
+    T.slots.erase(it);
+    return WJ_OK;
+}
+
 int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
     if (!wj_gemm_persist_eligible(a)) return WJ_ERR_UNSUPPORTED;
     SlotTable& T = table();
@@ -889,7 +905,10 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
         }
         auto it = T.slots.find(s);
         if (it == T.slots.end()) {
-            int fresh = (int)T.slots.size();
+            int fresh = -1;
+            for (int x = 0; x < SLOTS && fresh < 0; ++x)
+                if (T.released[x]) { fresh = x; T.released[x] = false; }      // a set its owner gave back (wj_gemm_release_stream)
+            if (fresh < 0) fresh = T.used < SLOTS ? T.used++ : SLOTS;
             if (fresh >= SLOTS) {
                 // Every counter set has an owner: hand the least recently used one whose stream is idle to the newcomer.  A set is back at
                 // zero whenever no launch of its stream is in flight (the last pull of a launch resets it), so an idle stream's set can change
@@ -898,7 +917,10 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
                 fresh = -1;
                 unsigned long long best = ~0ull;
                 for (int x = 0; x < SLOTS; ++x) {
-                    if (T.last_use[x] >= best) continue;
+                    if (T.last_use[x] >= best || !T.owner[x]) continue;
+                    // (a stream the host destroyed WITHOUT wj_gemm_release_stream: ROCm's hipStreamQuery checks the handle against its list
+                    // of live streams and answers with an error, which counts as idle here; a host that wants no query of a dead handle at
+                    // all releases its streams)
                     const hipError_t q = hipStreamQuery(T.owner[x]);
                     (void)hipGetLastError();
                     if (q == hipErrorNotReady) continue;           // work in flight on that stream: its counters may be live

@@ -359,10 +359,11 @@ class JepaEngine:
         # WJ_WT_DGRAD=0 keeps the col-form dgrads (A/B runs).
         self.wt_dgrad = _os.environ.get("WJ_WT_DGRAD", "1") != "0"
         # K-split pairs for the student's 117-tile GEMMs (scratch handed to the main-stream launches of that stack).  Round 6: OFF by default
-        # -- on the two-stream step they move nothing (46.85 / 46.87 ms in round 5, 46.09 with / 46.02 without in round 6, interleaved on one
-        # box) while costing 30 MB of partial sums per launch (traffic 1.31 x algorithmic) and a spin-wait between workgroups; a one-stream
-        # host gains 0.3 ms with WJ_PAIR_SPLIT=1 (or wj_gemm_args.workspace in its own calls).
-        self.pair_split = (_os.environ.get("WJ_PAIR_SPLIT", "0") == "1") if self.use_side else (_os.environ.get("WJ_PAIR_SPLIT", "1") != "0")
+        # (WJ_PAIR_SPLIT=1 enables) -- on the two-stream step they move nothing (46.85 / 46.87 ms in round 5, 46.09 with / 46.02 without in
+        # round 6, interleaved on one box) while costing 30 MB of partial sums per launch (traffic 1.31 x algorithmic) and a spin-wait between
+        # workgroups; a one-stream host (WJ_SIDE_STREAM=0) gains 0.3 ms with them.  One default for both, so that the serialised profile
+        # measures the kernels the timed step runs.
+        self.pair_split = _os.environ.get("WJ_PAIR_SPLIT", "0") == "1"
         self.pair_ws = None
         self._conv_w_fresh = False
         self.defer_folds = _os.environ.get("WJ_DEFER_FOLDS", "1") != "0"

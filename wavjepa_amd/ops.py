@@ -6,6 +6,7 @@ host and nothing falls back to PyTorch ops: a missing library or a non-zero retu
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Union
 
 import torch
@@ -188,6 +189,13 @@ def gemm_set_variant(variant: int) -> int:
     global _GEMM_SCHEDULE
     prev, _GEMM_SCHEDULE = _GEMM_SCHEDULE, (-1 if variant < 0 else int(variant))
     return prev
+
+
+def gemm_release_stream(stream: int) -> None:
+    """Hand the persistent GEMM's counter set of a stream that is about to be destroyed back to the library (optional; see the header)."""
+    rc = int(_abi.load().wj_gemm_release_stream(ctypes.c_void_p(int(stream))))
+    if rc != 0:
+        raise _abi.WavJepaHipError(f"wj_gemm_release_stream failed: {rc}")
 
 
 def transpose_bf16(src: Ptr, dst: Ptr, table: torch.Tensor, n_mats: int, n_tiles: int, stream: Optional[int] = None) -> None:
