@@ -313,270 +313,6 @@ __global__ __launch_bounds__(NT, 1) void gemm_panel_kernel(QArgs a) {
 }
 
 
-// ====================================================================================================================================
-// Version 2 of the loop (lab build: WJ_PANEL_V2=1 until it is measured): what tools/panel_diag.py said about version 1 --
-//   a step = 270 ns of barrier + LDS-DMA ISSUE (the W waves' four pieces, ~65 ns each) and THEN 225 ns of MFMAs, one after the other,
-//   because both waves of a SIMD are in the same phase and four of the eight waves carry three quarters of the pieces
-// -- turned into a schedule: (1) piece duty is uniform: a step is one 96-column QUARTER of W per K tile (12 pieces = 6 W waves x 2) and the
-// two A waves issue the 16 pieces of an A tile two per step over the four steps of a K tile, so EVERY wave issues exactly two pieces per
-// step; (2) a step has two phases, L (wait, barrier, issue two pieces, read the next step's fragments) and M (barrier, 12 MFMAs), and waves
-// 4-7 run ONE BARRIER behind waves 0-3: on every SIMD one wave multiplies while the other stages; (3) refills go to the slot whose fragments
-// were read TWO phases ago (W ring of six steps filled five ahead, A ring of four tiles filled three ahead), so no wave ever has to drain
-// its LDS reads before a barrier.  Waits are tied to the barrier INSTANCE (instance 2j: every W piece of step j + 1 has landed; instance
-// 8T + 6: every A piece of tile T + 1), which a wave of the lagging group meets one phase earlier in its own program.
-constexpr int QN = 4;                              // steps (96-column quarters) per K tile
-constexpr unsigned SLOT_W2 = 12288u;               // 96 rows of W x 128 B
-constexpr int NW2 = 6;                             // W ring slots
-constexpr unsigned A_RING2 = 0u, W_RING2 = 4u * SLOT;
-constexpr unsigned BIAS2 = W_RING2 + NW2 * SLOT_W2;
-constexpr unsigned STRIP2 = BIAS2 + 2048u;
-constexpr unsigned STRIP_ROW2 = 112u;              // 96 B of bf16 + 16
-constexpr int LDS_TOTAL2 = (int)(STRIP2 + 8u * 16u * STRIP_ROW2);
-constexpr int EPI_STORES2 = 2 * QN * 2;            // two store instructions per 16 x 48 block
-
-struct Cursor2 {
-    int b_kt, b_q;            // W: (K tile, quarter) of the next refill; periodic in the item
-    int a_it, a_kt, a_s;      // A: (item, K tile, quarter-of-the-pieces) of the next refill; the item is clamped past the last one
-};
-
-// one PHASE-L: [waits of this barrier instance][barrier][two pieces][fragments of step j + 1]
-// one PHASE-M: [waits of this barrier instance][barrier][MFMAs of step j]
-template <int SUB, int PB, int PA>
-__device__ __forceinline__ void step2(f32x4 (&acc)[2][3 * QN], bf16x8 (&af)[2][2][2], bf16x8 (&bf)[2][3][2], char* smem, const QArgs& a,
-                                      Cursor2& cur, unsigned& slot_w, unsigned& slot_a, unsigned& rd_w, unsigned& rd_a, int nk, int n_my,
-                                      int q0, int cstart, const unsigned (&voff)[2], unsigned piece_lds, long piece_src, unsigned a_rd,
-                                      unsigned b_rd, int role, bool g1, int& lag_w, int& lag_a, int rot) {
-    // role: 0..5 = W wave k (pieces 2k, 2k + 1 of every W step), 6 / 7 = A wave 0 / 1 (pieces 8a + 2s, 8a + 2s + 1 of the A tile, s = SUB)
-    const bool w_wave = role < 6;
-    // ---------------- phase L
-    __builtin_amdgcn_sched_barrier(0);
-    if (!g1) {                                          // (leading group: this barrier is instance 2j)
-        if (w_wave) {
-            if (lag_w > 0) { wait_vmcnt<6 + EPI_STORES2>(); --lag_w; } else wait_vmcnt<6>();
-        } else if constexpr (SUB == QN - 1) {
-            if (lag_a > 0) { wait_vmcnt<14 + EPI_STORES2>(); --lag_a; } else wait_vmcnt<14>();
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        // W step j + 5 -> the slot of step j - 1; A tile T + 3, two pieces per step -> the slot of tile T - 1
-        const int bk = cur.b_kt + rot < nk ? cur.b_kt + rot : cur.b_kt + rot - nk;
-        const char* sb = a.B + (long)(cur.b_q * 96) * a.ldb_b + (long)bk * 128 + piece_src;
-        const int it = cur.a_it < n_my ? cur.a_it : n_my - 1;
-        const int m0 = min((cstart + q0 + it * a.wpx) * 128, a.M - 128);
-        const int ak = cur.a_kt + rot < nk ? cur.a_kt + rot : cur.a_kt + rot - nk;
-        const char* sa = a.A + (long)m0 * a.lda_b + (long)ak * 128 + piece_src + (long)(16 * SUB) * a.lda_b;
-        const char* src = w_wave ? sb : sa;
-        const unsigned dst = w_wave ? W_RING2 + slot_w * SLOT_W2 + piece_lds : A_RING2 + slot_a * SLOT + piece_lds + (unsigned)(SUB * 2048);
-        dma(voff[0], src, dst);
-        dma(voff[1], src, dst + 1024u);
-        slot_w = slot_w + 1 == NW2 ? 0u : slot_w + 1;
-        if (++cur.b_q == QN) { cur.b_q = 0; if (++cur.b_kt == nk) cur.b_kt = 0; }
-        if constexpr (SUB == QN - 1) {
-            slot_a = (slot_a + 1) & 3;
-            if (++cur.a_kt == nk) { cur.a_kt = 0; ++cur.a_it; }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        rd_w = rd_w + 1 == NW2 ? 0u : rd_w + 1;            // the slot of step j + 1
-        const char* bs = smem + W_RING2 + rd_w * SLOT_W2;
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni) {
-            bf[PB ^ 1][ni][0] = *reinterpret_cast<const bf16x8*>(bs + b_rd + ni * 2048);
-            bf[PB ^ 1][ni][1] = *reinterpret_cast<const bf16x8*>(bs + (b_rd ^ 64u) + ni * 2048);
-        }
-    }
-    if constexpr (SUB == QN - 1) {
-        rd_a = (rd_a + 1) & 3;                             // the slot of K tile T + 1
-        const char* as = smem + A_RING2 + rd_a * SLOT;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            af[PA ^ 1][mi][0] = *reinterpret_cast<const bf16x8*>(as + a_rd + mi * 2048);
-            af[PA ^ 1][mi][1] = *reinterpret_cast<const bf16x8*>(as + (a_rd ^ 64u) + mi * 2048);
-        }
-    }
-    // ---------------- phase M
-    __builtin_amdgcn_sched_barrier(0);
-    if (g1) {                                           // (lagging group: this barrier is instance 2 (j + 1))
-        if (w_wave) {
-            if (lag_w > 0) { wait_vmcnt<6 + EPI_STORES2>(); --lag_w; } else wait_vmcnt<6>();
-        } else if constexpr (SUB == QN - 2) {
-            if (lag_a > 0) { wait_vmcnt<14 + EPI_STORES2>(); --lag_a; } else wait_vmcnt<14>();
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni) {
-            acc[mi][SUB * 3 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[PB][ni][0], af[PA][mi][0], acc[mi][SUB * 3 + ni], 0, 0, 0);
-            acc[mi][SUB * 3 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[PB][ni][1], af[PA][mi][1], acc[mi][SUB * 3 + ni], 0, 0, 0);
-        }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // phase L's fragment reads have long returned: their slots are free two phases on
-}
-
-// acc[mi][q * 3 + ni][r] = C[m0 + wm * 32 + mi * 16 + i][q * 96 + wn * 48 + ni * 16 + 4 g + r]
-__device__ __forceinline__ void epilogue2(f32x4 (&acc)[2][3 * QN], char* smem, const QArgs& a, int m0, int wave, int lane) {
-    const int wm = wave >> 1, wn = wave & 1;
-    const int i = lane & 15, g = lane >> 4;
-    char* strip = smem + STRIP2 + wave * (16 * STRIP_ROW2);
-    char* wr = strip + i * STRIP_ROW2 + g * 8;                                   // + ni * 32
-    const char* rd1 = strip + (lane >> 2) * STRIP_ROW2 + (lane & 3) * 16;                     // columns 0-31 of the block: 16 rows x 64 B
-    const char* rd2 = strip + ((lane & 31) >> 1) * STRIP_ROW2 + 64 + (lane & 1) * 16;          // columns 32-47: 16 rows x 32 B (lanes 0-31)
-    char* c1 = a.C + (long)(m0 + wm * 32 + (lane >> 2)) * a.ldc_b + (long)(wn * 48) * 2 + (lane & 3) * 16;
-    char* c2 = a.C + (long)(m0 + wm * 32 + ((lane & 31) >> 1)) * a.ldc_b + (long)(wn * 48) * 2 + 64 + (lane & 1) * 16;
-    const float* bias = reinterpret_cast<const float*>(smem + BIAS2) + wn * 48 + 4 * g;
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-        f32x4 bv[3];
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(bias + q * 96 + ni * 16);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 3; ++ni) {
-                const f32x4 v = acc[mi][q * 3 + ni] + bv[ni];
-                *reinterpret_cast<u32x2*>(wr + ni * 32) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-            }
-            __builtin_amdgcn_wave_barrier();
-            const u32x4 o1 = *reinterpret_cast<const u32x4*>(rd1);
-            const u32x4 o2 = *reinterpret_cast<const u32x4*>(rd2);
-            __builtin_amdgcn_wave_barrier();
-            const long off = (long)(mi * 16) * a.ldc_b + (long)(q * 96) * 2;
-            __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(c1 + off));
-            // (exactly ONE store instruction whatever the lane: the waits count it)
-            if (lane < 32) __builtin_nontemporal_store(o2, reinterpret_cast<u32x4*>(c2 + off));
-        }
-    }
-}
-
-__global__ __launch_bounds__(NT, 1) void gemm_panel2_kernel(QArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const bool g1 = wave >= 4;                          // waves 4-7 run one barrier behind
-    // staging roles: A waves = waves 0 and 5 (one per group), W waves = the other six in wave order
-    const int role = wave == 0 ? 6 : (wave == 5 ? 7 : (wave < 5 ? wave - 1 : wave - 2));
-    const bool w_wave = role < 6;
-    const int nk = a.K >> 6;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-
-    const int xl = blockIdx.x & 7, q0 = blockIdx.x >> 3;
-    const int qn = a.nitems >> 3, qr = a.nitems & 7;
-    const int clen = qn + (xl < qr ? 1 : 0);
-    const int cstart = xl < qr ? xl * (qn + 1) : qr * (qn + 1) + (xl - qr) * qn;
-    if (q0 >= clen) return;
-    const int n_my = (clen - q0 + a.wpx - 1) / a.wpx;
-    const int rot = (WJ_LAB_BUILD && (a.diag & 32)) ? (q0 + 3 * xl) % nk : 0;
-    auto phys = [&](int kt) { return kt + rot < nk ? kt + rot : kt + rot - nk; };
-
-    if (t < PN) reinterpret_cast<float*>(smem + BIAS2)[t] = a.bias ? a.bias[t] : 0.f;
-
-    // ---- piece geometry.  A piece = 8 rows x 128 B; this wave's two pieces of a step are rows [r0, r0 + 16) of the slot, r0 = 16 k for W
-    // wave k, 64 a + 16 s for A wave a in quarter s (the 16 s rows are a scalar term).  Lane -> row r0 + 8 u + lane / 8, LDS chunk position
-    // lane % 8 holding source chunk (lane % 8) ^ ((row >> 1) & 7) = (lane % 8) ^ (4 u + (lane / 8 >> 1))  (r0 is a multiple of 16).
-    const int l8 = lane >> 3;
-    const unsigned ld_b = w_wave ? a.ldb_b : a.lda_b;
-    unsigned voff[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-        voff[u] = (unsigned)(8 * u + l8) * ld_b + (unsigned)(((lane & 7) ^ ((4 * u + (l8 >> 1)) & 7)) * 16);
-    const int r0 = w_wave ? 16 * role : 64 * (role - 6);
-    const unsigned piece_lds = lds0 + (unsigned)r0 * 128u;
-    const long piece_src = (long)r0 * ld_b;
-    const int i = lane & 15, g = lane >> 4;
-    const unsigned sw = (unsigned)((g ^ ((i >> 1) & 7)) << 4);
-    const unsigned a_rd = (unsigned)((wm * 32 + i) * 128) + sw;
-    const unsigned b_rd = (unsigned)((wn * 48 + i) * 128) + sw;
-
-    // ---- prologue: A tiles 0-2 (every quarter of their pieces), W steps 0-4
-    {
-        const int m0 = min((cstart + q0) * 128, a.M - 128);
-        if (!w_wave) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int sq = 0; sq < QN; ++sq) {
-                    const char* sa = a.A + (long)m0 * a.lda_b + (long)phys(k) * 128 + piece_src + (long)(16 * sq) * a.lda_b;
-                    const unsigned dst = A_RING2 + k * SLOT + piece_lds + (unsigned)(sq * 2048);
-                    dma(voff[0], sa, dst);
-                    dma(voff[1], sa, dst + 1024u);
-                }
-        } else {
-#pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                const int kt = s5 / QN, qq = s5 - kt * QN;
-                const char* sb = a.B + (long)(qq * 96) * a.ldb_b + (long)phys(kt) * 128 + piece_src;
-                const unsigned dst = W_RING2 + s5 * SLOT_W2 + piece_lds;
-                dma(voff[0], sb, dst);
-                dma(voff[1], sb, dst + 1024u);
-            }
-        }
-    }
-    Cursor2 cur;
-    cur.b_kt = 1; cur.b_q = 1;                        // W step 5 = (K tile 1, quarter 1)
-    cur.a_it = 0; cur.a_kt = 3; cur.a_s = 0;          // A tile 3
-    if (cur.a_kt >= nk) { cur.a_kt -= nk; cur.a_it = 1; }
-    f32x4 acc[2][3 * QN];
-    bf16x8 af[2][2][2], bf[2][3][2];
-    // step 0's operands: W step 0 (younger: steps 1-4 = 8 instructions), A tile 0 (younger: tiles 1, 2 = 16 instructions)
-    if (w_wave) wait_vmcnt<8>(); else wait_vmcnt<16>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ni = 0; ni < 3; ++ni) {
-        bf[0][ni][0] = *reinterpret_cast<const bf16x8*>(smem + W_RING2 + b_rd + ni * 2048);
-        bf[0][ni][1] = *reinterpret_cast<const bf16x8*>(smem + W_RING2 + (b_rd ^ 64u) + ni * 2048);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        af[0][mi][0] = *reinterpret_cast<const bf16x8*>(smem + A_RING2 + a_rd + mi * 2048);
-        af[0][mi][1] = *reinterpret_cast<const bf16x8*>(smem + A_RING2 + (a_rd ^ 64u) + mi * 2048);
-    }
-    unsigned slot_w = 5, slot_a = 3;                  // next refill slots: W step 5 -> slot 5, A tile 3 -> slot 3
-    unsigned rd_w = 0, rd_a = 0;                      // slots of the step / K tile whose fragments are in registers
-    int lag_w = 0, lag_a = 0;
-    if (g1) {
-        // the lagging group meets barrier instance 0 here: its W waves vouch for step 1 as the leading group's do in their phase L(0)
-        if (w_wave) wait_vmcnt<6>();
-        __builtin_amdgcn_s_barrier();
-    }
-
-    for (int it = 0; it < n_my; ++it) {
-        const int m0 = min((cstart + q0 + it * a.wpx) * 128, a.M - 128);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int c = 0; c < 3 * QN; ++c) acc[mi][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; kt += 2) {
-#define WJ_STEP2(SUB, PB, PA) step2<SUB, PB, PA>(acc, af, bf, smem, a, cur, slot_w, slot_a, rd_w, rd_a, nk, n_my, q0, cstart, voff, piece_lds, \
-                                                 piece_src, a_rd, b_rd, role, g1, lag_w, lag_a, rot)
-            WJ_STEP2(0, 0, 0); WJ_STEP2(1, 1, 0); WJ_STEP2(2, 0, 0); WJ_STEP2(3, 1, 0);
-            WJ_STEP2(0, 0, 1); WJ_STEP2(1, 1, 1); WJ_STEP2(2, 0, 1); WJ_STEP2(3, 1, 1);
-#undef WJ_STEP2
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        epilogue2(acc, smem, a, m0, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        // waits whose awaited piece predates these stores: W: instances 2 (L + 1) .. 2 (L + 4) -- the leading group meets all four after its
-        // epilogue, the lagging group met the first one before it; A: the tiles of the next two K tiles
-        lag_w = g1 ? 3 : 4;
-        lag_a = 2;
-    }
-    if (!g1) __builtin_amdgcn_s_barrier();            // balance the lagging group's extra barrier
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-}
-
 }  // namespace
 
 bool wj_gemm_panel_eligible(const wj_gemm_args* a) {
@@ -605,16 +341,6 @@ int wj_gemm_panel_launch(const wj_gemm_args* a, hipStream_t s) {
     if (!lds_ok[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)gemm_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess) return WJ_ERR_LAUNCH;
         lds_ok[dev].store(true, std::memory_order_release);
-    }
-    if (wj_lab_env_int("WJ_PANEL_V2", 0)) {
-        static std::atomic<bool> lds_ok2[32];
-        if (!lds_ok2[dev].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute((const void*)gemm_panel2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2) != hipSuccess) return WJ_ERR_LAUNCH;
-            lds_ok2[dev].store(true, std::memory_order_release);
-        }
-        hipLaunchKernelGGL(gemm_panel2_kernel, dim3(8 * p.wpx), dim3(NT), LDS_TOTAL2, s, p);
-        WJ_CHECK_LAUNCH();
-        return WJ_OK;
     }
     hipLaunchKernelGGL(gemm_panel_kernel, dim3(8 * p.wpx), dim3(NT), LDS_TOTAL, s, p);
     WJ_CHECK_LAUNCH();
