@@ -2,7 +2,7 @@
 """DESIGN.md section 4's table from the committed profile of the round: every GEMM shape class of one training step -> the schedule
 that runs it -> launches x time -> rate -> fraction of the dense bf16 MFMA peak, plus the non-GEMM kernel classes with their HBM rates.
 
-    python3 tools/design_table.py profiles/r05_bench_gemm_shapes.json profiles/r05_serial_sum.txt > /tmp/table.md
+    python3 tools/design_table.py profiles/r06_bench_gemm_shapes.json profiles/r06_serial_sum.txt > /tmp/table.md
 
 The GEMM rows come from the instrumented step of bench.py (HIP events around every launch, streams serialised); the schedule column
 restates the selection rules of csrc/gemm.hip (pick_variant, pair_shape) and wavjepa_amd/engine.py (_row_form_pays, _pair_pays)."""
@@ -25,9 +25,7 @@ def schedule(kind, epi, M, N, K, gather):
     if K % 128 == 0 and items >= 256 and epi in ("BF16", "BIAS_GELU", "BIAS_GELU2", "CONV_GELU", "MUL_GELU_GRAD") and (N % 256 == 0 or N % 256 >= 128):
         return "persistent eight-phase 256x256x64" + (" + half-width items" if N % 256 == 128 else "")
     if K % 128 == 0 and N % 256 == 0:
-        if epi == "BF16" and K % 256 == 0 and K >= 1536 and 32 < tiles <= 128:
-            return "eight-phase 256x256x64, K-split PAIRS (2 workgroups per tile)"
-        return "eight-phase 256x256x64, one tile per workgroup"
+        return "eight-phase 256x256x64, one tile per workgroup"     # (K-split pairs: off by default since round 6)
     return "256x128, 2 workgroups/CU"
 
 
