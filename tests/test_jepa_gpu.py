@@ -989,7 +989,14 @@ def test_trainer_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     """Checkpoint / resume (reference train.py:244 `trainer.fit(..., ckpt_path=...)`; Lightning checkpoint keys): six steps straight
     through against three steps, a checkpoint, and a NEW process-like start (differently initialised model, fresh optimiser and
     scheduler) that resumes from it for the last three.  Parameters, EMA teacher, AdamW moments, step counter and learning rate
-    must land on the same values (the weight gradients' split-K sums are the only order-dependent arithmetic: 1e-5)."""
+    must land on the same values.  Two bounds, because the comparison has two regimes:
+      * ONE step past the restart (the step=4 checkpoints of both runs) the two runs started from bit-identical state, and the fp32
+        atomics of the weight gradients' split-K sums are the only order-dependent arithmetic: 1e-5 on everything.  A state that was
+        not carried over (moments, teacher, step counter, learning rate, bf16 shadows) shows here at O(1e-2..1).
+      * at step 6 that 1e-7 noise has been through two more updates: once in ~10 runs it carries one fp32 weight across a bf16
+        rounding boundary, that weight's bf16 shadow moves by 2^-8 and the next backward's gradients by ~1e-4 relative (seen once in a
+        full-suite run of round 6: adam_m 1.0e-4, parameters still < 1e-5; the masks come from OS entropy, so the draw differs per
+        run).  Parameters and teacher stay at 1e-5 (lr x the moments' difference); the moments get 5e-3."""
     from wavjepa_amd.data import SyntheticAudioSource
     from wavjepa_amd.masking import TimeInverseBlockMasker
     from wavjepa_amd.trainer import Trainer
@@ -1013,7 +1020,7 @@ def test_trainer_checkpoint_resume_continues_the_same_trajectory(tmp_path):
 
     def run(seed, root, ckpt=None, skip=0):
         m, _ = build(SMALL, seed=seed, warmup_steps=2)
-        tr = Trainer(max_steps=6, default_root_dir=str(root), checkpoint_every_n_steps=3, log_every_n_steps=0)
+        tr = Trainer(max_steps=6, default_root_dir=str(root), checkpoint_every_n_steps=1, log_every_n_steps=0)
         return m, tr.fit(m, train_dataloaders=loader(skip), ckpt_path=ckpt)
 
     ma, ra = run(7, tmp_path / "a")
@@ -1024,9 +1031,22 @@ def test_trainer_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     mb, rb = run(8, tmp_path / "b", ckpt=str(ck), skip=3)
     assert ma.global_step == mb.global_step == 6 and ra.optimizer._t == rb.optimizer._t == 6
     assert ra.scheduler.get_last_lr() == rb.scheduler.get_last_lr()
-    for name, a, b in (("student", ma._flat.p32, mb._flat.p32), ("teacher", ma._flat.t32, mb._flat.t32),
-                       ("adam_m", ma._flat.adam_m, mb._flat.adam_m), ("adam_v", ma._flat.adam_v, mb._flat.adam_v)):
-        assert rel(a, b) < 1e-5, (name, rel(a, b))
+    a4 = torch.load(tmp_path / "a" / "step=4.ckpt", map_location="cpu", weights_only=False)
+    b4 = torch.load(tmp_path / "b" / "step=4.ckpt", map_location="cpu", weights_only=False)
+    assert a4["global_step"] == b4["global_step"] == 4 and a4["optimizer"]["step"] == b4["optimizer"]["step"] == 4
+    assert a4["optimizer"]["lr"] == b4["optimizer"]["lr"] and a4["lr_scheduler"] == b4["lr_scheduler"]
+    assert set(a4["state_dict"]) == set(b4["state_dict"])
+    for k, va in a4["state_dict"].items():
+        vb = b4["state_dict"][k]
+        if va.is_floating_point() and va.numel() > 1 and float(va.float().norm()) > 0:
+            assert rel(va.float(), vb.float()) < 1e-5, ("step 4", k, rel(va.float(), vb.float()))
+        else:
+            assert torch.equal(va, vb), ("step 4", k)
+    for k in ("m", "v"):
+        assert rel(a4["optimizer"][k], b4["optimizer"][k]) < 1e-5, ("step 4", k, rel(a4["optimizer"][k], b4["optimizer"][k]))
+    for name, a, b, tol in (("student", ma._flat.p32, mb._flat.p32, 1e-5), ("teacher", ma._flat.t32, mb._flat.t32, 1e-5),
+                            ("adam_m", ma._flat.adam_m, mb._flat.adam_m, 5e-3), ("adam_v", ma._flat.adam_v, mb._flat.adam_v, 5e-3)):
+        assert rel(a, b) < tol, (name, rel(a, b))
 
 
 def test_state_dict_roundtrip_and_reference_checkpoint_layout():
