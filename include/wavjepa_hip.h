@@ -80,10 +80,11 @@ typedef struct {
                                 for 256 CUs) run as K-split PAIRS: two workgroups per tile, half of K each, fp32 partial sums exchanged
                                 through the scratch (csrc/gemm.hip).  NULL / too small: one workgroup per tile, as before. */
     int32_t schedule;        /* 0: the library picks the tile / schedule variant for the shape (csrc/gemm.hip: pick_variant).  1 + v: force variant
-                                v = 0..5 (4 = the persistent eight-phase kernel, 5 = the row-panel kernel for N = 384); a variant that cannot
-                                run the shape falls back to 3, then 0.
-                                Variants 0-3 and 5 give bit-identical outputs (same k order, bias added last); variant 4 starts its accumulators
-                                from the bias: a last-place difference of the bf16 output on <= 0.05 % of the elements.  Per call: the
+                                v = 0..6 (4 = the persistent eight-phase kernel, 5 = the row-panel kernel for N = 384, 6 = the persistent kernel
+                                with a deferred GELU epilogue, 128 x 256 items); a variant that cannot run the shape falls back (6 -> 4 -> 3 -> 0).
+                                Variants 0-3 and 5 give bit-identical outputs (same k order, bias added last); variants 4 and 6 start their
+                                accumulators from the bias: a last-place difference of the bf16 output on <= 0.05 % of the elements (4 and 6
+                                agree bit for bit).  Per call: the
                                 library keeps no selection state (tests and tools/gemm_check.py force each schedule this way). */
     int32_t persist_cus;     /* resident workgroups per XCD of the persistent schedule, 1..32; 0: the default (32 = one per CU, or the
                                 WJ_PERSIST_CUS environment variable read once at the first launch).  A data-parallel run (train.py:174-179:

@@ -282,6 +282,84 @@ def test_gemm_row_panel_schedule_for_thin_outputs(ops, M, K, cus, with_bias):
         assert relerr(Cbig[:, :N].float(), want) < 4e-3 and bool(torch.isnan(Cbig[:, N:].float()).all())
 
 
+@pytest.mark.parametrize("M,N,K,epi,cus", [(51200, 3072, 768, "gelu", None),     # the teacher's linear1
+                                            (86317, 1536, 384, "gelu2", None),     # the predictor's linear1 (ragged rows: a shifted last panel)
+                                            (9907, 3072, 768, "gelu2", 28),        # the student's linear1; 28 resident workgroups per XCD
+                                            (16640, 1024, 256, "gelu2", None),     # four K tiles: every K tile of an item carries a block
+                                            (102912, 512, 1536, "conv", None),     # a sparse conv layer (402-row segments, 400 valid)
+                                            (33000, 512, 1024, "conv", 5),         # few resident workgroups: long item queues
+                                            (65664, 256, 512, "gelu", None)])      # one item per panel
+def test_gemm_deferred_epilogue_schedule(ops, M, N, K, epi, cus):
+    """Variant 6 (csrc/gemm_pde.hip): 128 x 256 work items whose GELU epilogue is deferred -- the finished tile is parked as packed bf16 and
+    taken through GELU / the stores in four blocks inside the next item's K loop (reference jepa.py:129-131 + the transformer MLPs; conv
+    layers of extractors/audio_feature_extractor.py:54-138).  On NaN-filled outputs: against fp32 torch math, and BIT-IDENTICAL to the
+    persistent 256 x 256 kernel (same k order, accumulators started from the bias, same GELU code), to itself across launches and across the
+    number of resident workgroups."""
+    A = rnd(M, K, dtype=torch.bfloat16, seed=81)
+    W = rnd(N, K, scale=0.06, dtype=torch.bfloat16, seed=82)
+    bias = rnd(N, seed=83)
+    code = {"gelu": ops.EPI_BIAS_GELU, "gelu2": ops.EPI_BIAS_GELU2, "conv": ops.EPI_CONV_GELU}[epi]
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=code)
+    if epi == "conv":
+        kw.update(seg_rows=402, seg_valid=400)
+    else:
+        kw["bias"] = bias
+
+    def run(variant, n_cus=None):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+        C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev()) if epi != "gelu" else None
+        ops.gemm(A, W, C, C2=C2, schedule=variant, persist_cus=n_cus, **kw)
+        torch.cuda.synchronize()
+        return C, C2
+
+    C6, C6b = run(6, cus)
+    h = (A.float() @ W.float().t() + (bias if epi != "conv" else 0.0)).to(torch.bfloat16).float()
+    if epi == "conv":
+        valid = (torch.arange(M, device=dev()) % 402 < 400).float()[:, None]
+        assert relerr(C6.float(), h * valid) < 4e-3                                        # C = pre-activation, C2 = GELU, rows outside the segments 0
+        assert relerr(C6b.float(), F.gelu(h) * valid) < 6e-3
+        assert float(C6.float()[401::402].abs().max()) == 0.0 and float(C6b.float()[400::402].abs().max()) == 0.0
+    elif epi == "gelu2":
+        gp = 0.5 * (1 + torch.erf(h / math.sqrt(2))) + h * torch.exp(-0.5 * h * h) / math.sqrt(2 * math.pi)
+        assert relerr(C6.float(), gp) < 6e-3                                               # C = gelu'(h), C2 = gelu(h)
+        assert relerr(C6b.float(), F.gelu(h)) < 6e-3
+    else:
+        assert relerr(C6.float(), F.gelu(h)) < 6e-3
+    C4, C4b = run(4)
+    assert torch.equal(C6.view(torch.int16), C4.view(torch.int16))
+    assert C6b is None or torch.equal(C6b.view(torch.int16), C4b.view(torch.int16))
+    for n_cus in (cus, 32, 11):
+        Cx, Cxb = run(6, n_cus)
+        assert torch.equal(Cx.view(torch.int16), C6.view(torch.int16)), n_cus
+        assert C6b is None or torch.equal(Cxb.view(torch.int16), C6b.view(torch.int16)), n_cus
+
+
+def test_gemm_deferred_epilogue_repeated_launches_beside_another_stream(ops):
+    """60 launches of the deferred-epilogue kernel on two streams at once (each workgroup then finds its CU shared or late and pulls fewer
+    items), into NaN-filled outputs: every launch gives the first one's bits.  A wait that counted one store too many or too few shows as
+    stale operand tiles in a few items."""
+    M, N, K = 86317, 1536, 384
+    A = rnd(M, K, dtype=torch.bfloat16, seed=84)
+    W = rnd(N, K, scale=0.06, dtype=torch.bfloat16, seed=85)
+    bias = rnd(N, seed=86)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epilogue=ops.EPI_BIAS_GELU2, bias=bias, schedule=6)
+    ref, ref2 = (torch.empty(M, N, dtype=torch.bfloat16, device=dev()) for _ in range(2))
+    ops.gemm(A, W, ref, C2=ref2, **kw)
+    torch.cuda.synchronize()
+    outs = [(torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev()), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev()))
+            for _ in range(4)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(15):
+        for j, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                for q in range(2):
+                    ops.gemm(A, W, outs[2 * j + q][0], C2=outs[2 * j + q][1], **kw)
+        torch.cuda.synchronize()
+        for o, o2 in outs:
+            assert torch.equal(o.view(torch.int16), ref.view(torch.int16)) and torch.equal(o2.view(torch.int16), ref2.view(torch.int16)), rep
+            o.fill_(float("nan")); o2.fill_(float("nan"))
+
+
 def test_gemm_row_panel_repeated_launches_are_bit_identical(ops):
     """60 launches of the row-panel kernel into NaN-filled outputs (two streams alternating): every one gives the first one's bits."""
     M, N, K = 87000, 384, 1152

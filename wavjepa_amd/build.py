@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libwavjepa_hip.so")
 LAB_LIB = os.path.join(LIBDIR, "libwavjepa_hip_lab.so")      # the same sources with -DWJ_LAB (include/wavjepa_hip_lab.h): diagnostics + A/B switches
-SOURCES = ["gemm.hip", "gemm_persist.hip", "gemm_panel.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip", "rccl_bucket.hip"]
+SOURCES = ["gemm.hip", "gemm_persist.hip", "gemm_pde.hip", "gemm_panel.hip", "norm.hip", "attention.hip", "conv0.hip", "misc.hip", "fp8.hip", "scene.hip", "denoise.hip", "rccl_bucket.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 
 

@@ -1292,6 +1292,8 @@ int launch(const wj_gemm_args* a, hipStream_t s) {
 //   4 = variant 3's loop, persistent     : >= 256 work items; forward epilogues, plain BF16 and MUL_GELU_GRAD (+ column sums) for the
 //                                          row-form dgrads against W^T shadows (csrc/gemm_persist.hip)
 //   5 = row panels, 128 x 384 items      : N = 384, row-form operands, plain BF16 (csrc/gemm_panel.hip)
+//   6 = persistent, deferred epilogue    : 128 x 256 items, the GELU of item i under the K loop of item i + 1 (csrc/gemm_pde.hip): the
+//                                          GELU epilogues (BIAS_GELU, BIAS_GELU2, CONV_GELU) with N % 256 == 0, K >= 256, >= 512 items
 // wj_gemm_args.schedule = 1 + v forces variant v for that call (tests, tools/gemm_check.py; 1-3 need N % 256 == 0 to avoid wasted columns
 // but stay correct; a variant that cannot run a shape falls back to 3, then 0); the lab build also honours WJ_GEMM_VARIANT=v for calls
 // that leave the field 0.  The library keeps no selection state.
@@ -1304,10 +1306,17 @@ bool panel_auto() {
     return on != 0;
 }
 
+bool pde_auto() {
+    static const int on = wj_lab_env_int("WJ_GEMM_PDE", 0);
+    return on != 0;
+}
+
 int pick_variant(const wj_gemm_args* a) {
     static const int env_forced = wj_lab_env_int("WJ_GEMM_VARIANT", -1);
     const int forced = a->schedule > 0 ? a->schedule - 1 : env_forced;
     const bool ep_ok = !a->a_trans && !a->b_trans && a->K % 128 == 0 && a->split_k <= 1;   // eight-phase schedule (variant 3)
+    if (forced == 6) return wj_gemm_pde_eligible(a) ? 6 : (wj_gemm_persist_eligible(a) ? 4 : (ep_ok ? 3 : 0));
+    if (forced < 0 && pde_auto() && wj_gemm_pde_eligible(a)) return 6;
     if (forced == 5) return wj_gemm_panel_eligible(a) ? 5 : (ep_ok ? 3 : 0);
     if (forced == 4) return wj_gemm_persist_eligible(a) ? 4 : (ep_ok ? 3 : 0);
     if (forced == 3) return ep_ok ? 3 : 0;
@@ -1330,6 +1339,11 @@ int pick_variant(const wj_gemm_args* a) {
 template <bool AT, bool BT, int EPI>
 int launch_bn(const wj_gemm_args* a, hipStream_t s) {
     int v = pick_variant(a);
+    if (v == 6) {
+        const int rc = wj_gemm_pde_launch(a, s);
+        if (rc != WJ_ERR_UNSUPPORTED) return rc;
+        v = wj_gemm_persist_eligible(a) ? 4 : 3;
+    }
     if (v == 5) {
         if constexpr (!AT && !BT && EPI == WJ_EPI_BF16) {
             const int rc = wj_gemm_panel_launch(a, s);
@@ -1487,7 +1501,7 @@ extern "C" int wj_gemm_bf16(const wj_gemm_args* a, void* stream) {
     if (a->epilogue == WJ_EPI_MUL_GELU_GRAD_Z && (!a->aux || !a->rowmap || ((uintptr_t)a->aux & 15))) return WJ_ERR_ARG;
     if (a->split_k > 1 && a->epilogue != WJ_EPI_ATOMIC_F32) return WJ_ERR_ARG;
     if (a->colsum && a->epilogue != WJ_EPI_BF16 && a->epilogue != WJ_EPI_MUL_GELU_GRAD) return WJ_ERR_ARG;
-    if (a->schedule < 0 || a->schedule > 6 || a->persist_cus < 0 || a->persist_cus > 32) return WJ_ERR_ARG;
+    if (a->schedule < 0 || a->schedule > 7 || a->persist_cus < 0 || a->persist_cus > 32) return WJ_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (a->rowmap) {
         // gather forms (sparse conv backward), one instantiation each

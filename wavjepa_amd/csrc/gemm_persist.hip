@@ -110,6 +110,16 @@ __device__ __forceinline__ void wait_lag(int lag) {
 
 // One LDS-DMA instruction: 64 lanes x 16 B from sbase + voff (per lane) to LDS bytes [lds_wave + LDS_CONST + 16 lane).
 // M0 is written here and nowhere else in this kernel (no builtin LDS-DMA is left in it).
+// One dword from LDS byte address `addr` (the kernel's only LDS is the dynamic block at 0).  From asm: a `volatile` C++ read of the mailbox is
+// not rewritten to the LDS address space by hipcc -- it became a FLAT load, and a flat load is waited for with vmcnt(0): every item boundary
+// drained the epilogue's stores and the staged LDS-DMA pieces that the counted waits of the next K tiles are there to leave in flight
+// (found in round 6 in the ISA of the round-3 kernel).
+__device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
 template <unsigned LDS_CONST>
 __device__ __forceinline__ void dma(unsigned voff, const char* sbase, unsigned lds_wave) {
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -643,7 +653,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
                      ::"v"(pv), "v"(MAILBOX) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    unsigned mail_v = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
+    unsigned mail_v = lds_read_u32(MAILBOX);
     mail_v = __builtin_amdgcn_readfirstlane(mail_v);
     if (mail_v == (unsigned)(clen - 1) && t == 0) atomicExch(ctr, 0u);   // the launch's last pull on this counter: reset it
     int q_next = a.wpx + (int)mail_v;
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_persist_kernel(PArgs a) {
         if (pulled) {
             // the word wave 0 wrote in the second K tile of the tile just finished (>= 2 barriers ago for either wave group; the next
             // write is a K tile away)
-            unsigned mv = *reinterpret_cast<volatile unsigned*>(smem + MAILBOX);
+            unsigned mv = lds_read_u32(MAILBOX);
             mv = __builtin_amdgcn_readfirstlane(mv);
             if (mv == (unsigned)(clen - 1) && t == 0) atomicExch(ctr, 0u);
             q_next = a.wpx + (int)mv;
@@ -762,7 +772,8 @@ Items items_of(const wj_gemm_args* a) {
 // Resident workgroups per XCD: wj_gemm_args.persist_cus (1..32) per call; 0 = the default, 32 = one per CU, or WJ_PERSIST_CUS=n read ONCE
 // (thread-safe static initialisation; no state that a later call can change).  A data-parallel run passes a value below 32 so that an RCCL
 // channel kernel finds free CUs while a persistent GEMM is resident (trainer.init_persist_cus).
-int persist_wpx(const wj_gemm_args* a) {
+}  // namespace
+int wj_gemm_persist_wpx(const wj_gemm_args* a) {
     static const int dflt = [] {
         const char* v = getenv("WJ_PERSIST_CUS");
         const int w = v ? atoi(v) : 32;
@@ -770,6 +781,7 @@ int persist_wpx(const wj_gemm_args* a) {
     }();
     return a->persist_cus > 0 ? (a->persist_cus > 32 ? 32 : a->persist_cus) : dflt;
 }
+namespace {
 
 // Start-up spread in ticks of the 100 MHz clock (lab build only).  WJ_PERSIST_STAGGER_US=<us> applies to every launch; unset: 0.
 int persist_stagger(const wj_gemm_args* a) {
@@ -790,7 +802,7 @@ int launch_persist(const wj_gemm_args* a, hipStream_t s, unsigned* ctr, int dev)
     const Items it = items_of(a);
     p.items_n = it.items_n; p.half_item = it.half_item;
     p.ntiles = ((a->M + 255) / 256) * p.items_n;
-    p.wpx = persist_wpx(a);
+    p.wpx = wj_gemm_persist_wpx(a);
     p.stagger = persist_stagger(a);
     {
         // Blocked tile order for shapes with N >= 2304 whose per-XCD run of items is whole panels and whose item count per panel is a
@@ -890,17 +902,18 @@ extern "C" int wj_gemm_release_stream(void* stream) {
     return WJ_OK;
 }
 
-int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
-    if (!wj_gemm_persist_eligible(a)) return WJ_ERR_UNSUPPORTED;
+// The counter set of a stream (8 counters, one 128-B line each, all zero between launches): shared by the persistent kernels of this file
+// and of csrc/gemm_pde.hip -- launches of one stream run in order, and every launch leaves its counters at zero.
+unsigned* wj_gemm_persist_counters(hipStream_t s, int* dev_out) {
     SlotTable& T = table();
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return WJ_ERR_UNSUPPORTED;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     int slot;
     {
         std::lock_guard<std::mutex> lk(T.mu);
         if (!T.base[dev]) {
             void* p = nullptr;
-            if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_ctr)) != hipSuccess) { (void)hipGetLastError(); return WJ_ERR_UNSUPPORTED; }
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_ctr)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             T.base[dev] = (unsigned*)p;
         }
         auto it = T.slots.find(s);
@@ -927,7 +940,7 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
                     best = T.last_use[x];
                     fresh = x;
                 }
-                if (fresh < 0) return WJ_ERR_UNSUPPORTED;           // 64 streams with persistent GEMMs in flight at once
+                if (fresh < 0) return nullptr;                      // 64 streams with persistent GEMMs in flight at once
                 T.slots.erase(T.owner[fresh]);
             }
             T.owner[fresh] = s;
@@ -936,7 +949,15 @@ int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
         slot = it->second;
         T.last_use[slot] = ++T.seq;
     }
-    unsigned* ctr = T.base[dev] + (size_t)slot * 8 * CTR_STRIDE;
+    if (dev_out) *dev_out = dev;
+    return T.base[dev] + (size_t)slot * 8 * CTR_STRIDE;
+}
+
+int wj_gemm_persist_launch(const wj_gemm_args* a, hipStream_t s) {
+    if (!wj_gemm_persist_eligible(a)) return WJ_ERR_UNSUPPORTED;
+    int dev = 0;
+    unsigned* ctr = wj_gemm_persist_counters(s, &dev);
+    if (!ctr) return WJ_ERR_UNSUPPORTED;
     switch (a->epilogue) {
         case WJ_EPI_BF16: return launch_persist<WJ_EPI_BF16>(a, s, ctr, dev);
         case WJ_EPI_BIAS_GELU2: return launch_persist<WJ_EPI_BIAS_GELU2>(a, s, ctr, dev);
