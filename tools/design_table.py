@@ -57,8 +57,17 @@ def main():
             continue
         shown += ms
         intensity = K / (2.0 if epi in ("BIAS_GELU2", "MUL_GELU_GRAD", "CONV_GELU") else 1.0)        # flops per output byte ~ 2K / (2 or 4)
-        bound = "HBM (two bf16 tensors per output)" if K <= 512 and epi in ("BIAS_GELU2", "MUL_GELU_GRAD") else (
-            "HBM / epilogue (K = 384: 6 K tiles per item)" if K <= 512 else ("MFMA + tile count (fills < 256 CUs)" if -(-M // 256) * -(-N // 256) < 200 and kind != "TT" else "MFMA"))
+        few = -(-M // 256) * -(-N // 256) < 200 and kind != "TT"
+        if epi == "BIAS_GELU2" and K <= 512:
+            bound = "epilogue VALU (erf-GELU and GELU': ~20 issue slots per output, 13 of an item's 23 us) + 2 bf16 stores per output"
+        elif epi == "MUL_GELU_GRAD" and K <= 512:
+            bound = "epilogue (a gelu' tile read + a product tile written per item, column sums) on 6 K tiles per item"
+        elif K <= 512:
+            bound = "operand delivery / epilogue (K = 384: 6 K tiles per item)"
+        elif epi in ("BIAS_GELU", "BIAS_GELU2", "CONV_GELU") and not few:
+            bound = "MFMA, then epilogue VALU with the matrix pipe idle (erf-GELU: 7 of an item's 27-30 us)"
+        else:
+            bound = "MFMA + tile count (fills < 256 CUs)" if few else "MFMA"
         print(f"| `{kind},{epi}` {M}x{N}x{K}{' gather' if gather else ''} ({who(M, N, K, epi, gather)}) | {schedule(kind, epi, M, N, K, gather)} | "
               f"{v['launches']} x {v['us_per_launch']:.0f} | {v['tflops']:.0f} | {v['tflops'] / PEAK:.2f} | {bound} |")
     rest = sum(r[0] for r in rows) - shown
